@@ -1,0 +1,140 @@
+/*
+ * shakti_hip.h -- C ABI of the MI355X (gfx950) SHAKTI hot-path library, libshakti_hip.so.
+ *
+ * The reference has no native/FFI boundary: its solve loop is Python driving DOLFINx/PETSc
+ * (/root/reference/source/solvers.py).  This header is the boundary this build introduces
+ * *underneath* the reference's Python API; each entry point names the reference lines whose
+ * work it replaces.  The Python mirror of the reference API that calls it lives in
+ * shakti_fenics_amd/solvers.py (ctypes binding: shakti_fenics_amd/_lib.py, and INTEGRATION.md).
+ *
+ * Conventions
+ *  - every function returns int: 0 = ok, negative = error (text via shk_last_error(), thread-local);
+ *  - shk_ctx is opaque; one context per GPU (per subdomain); a context is not thread-safe;
+ *  - the caller owns all host arrays (borrowed for the duration of the call, C-contiguous,
+ *    float64 / int32); the library owns all device memory;
+ *  - vertex fields are length nv; SHK_Q is length 2*nv interleaved [x0,y0,x1,y1,...] (DOLFINx's
+ *    blocked P1-vector layout, solvers.py:130,139-140);
+ *  - all arithmetic is float64 (PETSc.ScalarType, solvers.py:24).
+ */
+#ifndef SHAKTI_HIP_H
+#define SHAKTI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct shk_ctx shk_ctx;
+
+/* Physical constants = /root/reference/source/params.py:4-11; b_min = model_setup.py:53;
+ * Newton knobs = the DOLFINx NewtonSolver defaults the reference never overrides
+ * (solvers.py:52); Krylov knobs belong to this build (the reference uses LU). */
+typedef struct shk_params {
+    double g, rho_i, rho_w, nu, Lh, omega, n, A;
+    double b_min;
+    double newton_rtol, newton_atol, newton_relax;
+    double krylov_rtol, krylov_atol;
+    int32_t newton_max_it;
+    int32_t krylov_max_it;
+    int32_t krylov_check_every; /* iterations enqueued between host convergence polls */
+    int32_t reserved;
+} shk_params;
+
+enum shk_field {
+    SHK_N = 0,       /* effective pressure, the Newton unknown          (solvers.py:129) */
+    SHK_N_N = 1,     /* N at the previous time step                     (solvers.py:134) */
+    SHK_B = 2,       /* gap height                                      (solvers.py:131) */
+    SHK_Q = 3,       /* water flux, 2*nv interleaved                    (solvers.py:130) */
+    SHK_Z_B = 4,     /* bed elevation                                   (model_setup.py:44) */
+    SHK_Z_S = 5,     /* surface elevation                               (model_setup.py:45) */
+    SHK_G = 6,       /* geothermal heat flux                            (model_setup.py:46) */
+    SHK_MELT_N = 7,  /* lagged melt rate                                (solvers.py:156) */
+    SHK_STORAGE = 8, /* lake storage indicator                          (solvers.py:147-152) */
+    SHK_INPUTS = 9,  /* moulin inputs                                   (model_setup.py:47) */
+    SHK_QX = 10,     /* x component of q, length nv                     (solvers.py:144) */
+    SHK_QY = 11,     /* y component of q, length nv                     (solvers.py:145) */
+    SHK_DX = 12,     /* last Newton increment (read-only diagnostic) */
+    SHK_FIELD_COUNT = 13
+};
+
+typedef struct shk_solve_info {
+    int32_t newton_its;      /* NewtonSolver.solve's niter              (solvers.py:179) */
+    int32_t converged;       /* ... and its converged flag */
+    int32_t krylov_its;      /* BiCGStab iterations summed over the Newton iterations */
+    int32_t krylov_failed;   /* 1 if a linear solve hit max_it or broke down */
+    double residual0;        /* ||F|| before the first Newton iteration */
+    double residual;         /* ||F|| at exit */
+} shk_solve_info;
+
+/* Device-side timings accumulated with hipEvents on the library's stream while profiling is on. */
+enum shk_phase {
+    SHK_PH_ASSEMBLE = 0, SHK_PH_SPMV = 1, SHK_PH_VECTOR = 2, SHK_PH_UPDATE = 3, SHK_PH_OTHER = 4,
+    SHK_PH_HALO = 5, SHK_PH_COUNT = 6
+};
+typedef struct shk_profile {
+    double ms[SHK_PH_COUNT];      /* summed launch durations per phase */
+    int64_t launches[SHK_PH_COUNT];
+} shk_profile;
+
+const char* shk_last_error(void);
+int shk_version(void);
+
+/* Upload the mesh, build the P1 CSR pattern and the static assembly / SpMV plans.
+ * Replaces mesh + function-space + matrix preallocation: setup_cooke2.py:19, model_setup.py:29-30,
+ * solvers.py:51-52.  xy is (nv,2), cells is (ne,3); cell order defines "last cell wins". */
+int shk_create(int device_id, int64_t nv, int64_t ne, const double* xy, const int32_t* cells, shk_ctx** out);
+int shk_destroy(shk_ctx* ctx);
+
+int shk_default_params(shk_params* p);
+int shk_set_params(shk_ctx* ctx, const shk_params* p);
+int shk_get_params(shk_ctx* ctx, shk_params* p);
+
+/* Quadrature on the reference triangle, xyw = (nq,3) rows x,y,w with sum(w) = 1/2; nq <= 32.
+ * Default: the 15-point degree-7 rule of csrc/shk_quadrature.h (stands in for Basix's table). */
+int shk_set_quadrature(shk_ctx* ctx, int32_t nq, const double* xyw);
+
+int shk_set_field(shk_ctx* ctx, int32_t field, const double* host);
+int shk_get_field(shk_ctx* ctx, int32_t field, double* host);
+
+/* get_bcs (solvers.py:17-26): constant Dirichlet value on the listed dofs; n = 0 clears (outflow_on False). */
+int shk_set_dirichlet(shk_ctx* ctx, int64_t n, const int32_t* dofs, double value);
+
+/* Residual + Jacobian of the weak form solvers.py:35-45 with DOLFINx's Dirichlet algebra, one fused
+ * element pass.  Exposed for parity tests. */
+int shk_assemble(shk_ctx* ctx, double dt);
+int shk_get_residual(shk_ctx* ctx, double* host);
+int shk_csr_nnz(shk_ctx* ctx, int64_t* nnz);
+int shk_get_csr(shk_ctx* ctx, int32_t* rowptr, int32_t* colidx, double* values);
+
+/* Solve J dx = F for the system last assembled (Jacobi-preconditioned BiCGStab); dx via SHK_DX. */
+int shk_linear_solve(shk_ctx* ctx, int32_t* its, int32_t* converged, double* rel_residual);
+
+/* y = J x with the assembled Jacobian (unscaled) -- parity / roofline probe of the SpMV kernel. */
+int shk_spmv(shk_ctx* ctx, const double* x_host, double* y_host);
+
+/* NewtonSolver.solve(N) (solvers.py:179): updates SHK_N in place. */
+int shk_newton_solve(shk_ctx* ctx, double dt, shk_solve_info* info);
+
+/* q, melt_n, b interpolations + clamp + N_n <- N (solvers.py:186-197,228-229). */
+int shk_update_explicit(shk_ctx* ctx, double dt);
+
+/* One time step: shk_newton_solve then shk_update_explicit (solvers.py:179-197,228-229). */
+int shk_step(shk_ctx* ctx, double dt, shk_solve_info* info);
+
+int shk_sync(shk_ctx* ctx);
+
+/* Profiling: per-launch hipEvent pairs on the library's stream, summed per phase. */
+int shk_profile_enable(shk_ctx* ctx, int32_t on);
+int shk_profile_read(shk_ctx* ctx, shk_profile* out, int32_t reset);
+/* Launch kernel `phase` (SHK_PH_ASSEMBLE or SHK_PH_SPMV) `reps` times between two events. */
+int shk_time_kernel(shk_ctx* ctx, int32_t phase, int32_t reps, double dt, double* avg_ms);
+
+/* Plan statistics for DESIGN.md / bench: n[0]=nv n[1]=ne n[2]=nnz n[3]=assembly blocks
+ * n[4]=cells computed incl. redundant n[5]=spmv row blocks n[6]=device bytes n[7]=max row length */
+int shk_plan_stats(shk_ctx* ctx, int64_t n[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHAKTI_HIP_H */

@@ -1,0 +1,243 @@
+"""ctypes binding of libshakti_hip.so (C ABI: include/shakti_hip.h).
+
+There is no CPU fallback: if the library is missing, or no MI355X is visible, every entry point
+raises.  Build the library with `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C shakti_fenics_amd/csrc`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libshakti_hip.so")
+
+
+class ShaktiHipError(RuntimeError):
+    pass
+
+
+class shk_params(C.Structure):
+    _fields_ = [(n, C.c_double) for n in
+                ("g", "rho_i", "rho_w", "nu", "Lh", "omega", "n", "A", "b_min",
+                 "newton_rtol", "newton_atol", "newton_relax", "krylov_rtol", "krylov_atol")] + \
+               [(n, C.c_int32) for n in ("newton_max_it", "krylov_max_it", "krylov_check_every", "reserved")]
+
+
+class shk_solve_info(C.Structure):
+    _fields_ = [("newton_its", C.c_int32), ("converged", C.c_int32), ("krylov_its", C.c_int32),
+                ("krylov_failed", C.c_int32), ("residual0", C.c_double), ("residual", C.c_double)]
+
+
+PHASES = ("assemble", "spmv", "vector", "update", "other", "halo")
+
+
+class shk_profile(C.Structure):
+    _fields_ = [("ms", C.c_double * len(PHASES)), ("launches", C.c_int64 * len(PHASES))]
+
+
+FIELDS = dict(N=0, N_n=1, b=2, q=3, z_b=4, z_s=5, G=6, melt_n=7, storage=8, inputs=9, qx=10, qy=11, dx=12)
+
+# every symbol include/shakti_hip.h declares (tests/test_abi.py checks the .so exports all of them)
+EXPORTS = (
+    "shk_last_error", "shk_version", "shk_create", "shk_destroy", "shk_default_params", "shk_set_params",
+    "shk_get_params", "shk_set_quadrature", "shk_set_field", "shk_get_field", "shk_set_dirichlet",
+    "shk_assemble", "shk_get_residual", "shk_csr_nnz", "shk_get_csr", "shk_linear_solve", "shk_spmv",
+    "shk_newton_solve", "shk_update_explicit", "shk_step", "shk_sync", "shk_profile_enable",
+    "shk_profile_read", "shk_time_kernel", "shk_plan_stats",
+)
+
+_lib = None
+
+
+def load():
+    """Load the HIP library or raise -- never falls back to a CPU path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ShaktiHipError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run __graft_entry__.build() or make -C shakti_fenics_amd/csrc); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    lib.shk_last_error.restype = C.c_char_p
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    P = C.POINTER
+    sig = {
+        "shk_version": ([], C.c_int),
+        "shk_create": ([C.c_int, i64, i64, vp, vp, P(vp)], C.c_int),
+        "shk_destroy": ([vp], C.c_int),
+        "shk_default_params": ([P(shk_params)], C.c_int),
+        "shk_set_params": ([vp, P(shk_params)], C.c_int),
+        "shk_get_params": ([vp, P(shk_params)], C.c_int),
+        "shk_set_quadrature": ([vp, i32, vp], C.c_int),
+        "shk_set_field": ([vp, i32, vp], C.c_int),
+        "shk_get_field": ([vp, i32, vp], C.c_int),
+        "shk_set_dirichlet": ([vp, i64, vp, dbl], C.c_int),
+        "shk_assemble": ([vp, dbl], C.c_int),
+        "shk_get_residual": ([vp, vp], C.c_int),
+        "shk_csr_nnz": ([vp, P(i64)], C.c_int),
+        "shk_get_csr": ([vp, vp, vp, vp], C.c_int),
+        "shk_linear_solve": ([vp, P(i32), P(i32), P(dbl)], C.c_int),
+        "shk_spmv": ([vp, vp, vp], C.c_int),
+        "shk_newton_solve": ([vp, dbl, P(shk_solve_info)], C.c_int),
+        "shk_update_explicit": ([vp, dbl], C.c_int),
+        "shk_step": ([vp, dbl, P(shk_solve_info)], C.c_int),
+        "shk_sync": ([vp], C.c_int),
+        "shk_profile_enable": ([vp, i32], C.c_int),
+        "shk_profile_read": ([vp, P(shk_profile), i32], C.c_int),
+        "shk_time_kernel": ([vp, i32, i32, dbl, P(dbl)], C.c_int),
+        "shk_plan_stats": ([vp, P(i64)], C.c_int),
+    }
+    for name, (args, res) in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = res
+    _lib = lib
+    return lib
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a, shape=None) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != shape:
+        raise ValueError(f"expected array of shape {shape}, got {a.shape}")
+    return a
+
+
+class ShaktiHip:
+    """One device context: mesh + fields + solver state resident in HBM."""
+
+    def __init__(self, xy, cells, device: int = 0):
+        self.lib = load()
+        xy = _f64(xy)
+        cells = np.ascontiguousarray(cells, dtype=np.int32)
+        if xy.ndim != 2 or xy.shape[1] != 2 or cells.ndim != 2 or cells.shape[1] != 3:
+            raise ValueError("xy must be (nv,2) float64 and cells (ne,3) int32")
+        self.nv, self.ne = xy.shape[0], cells.shape[0]
+        h = C.c_void_p()
+        self._check(self.lib.shk_create(device, self.nv, self.ne, _ptr(xy), _ptr(cells), C.byref(h)))
+        self._h = h
+
+    def _check(self, rc):
+        if rc != 0:
+            raise ShaktiHipError(self.lib.shk_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.shk_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- parameters
+    def get_params(self) -> shk_params:
+        p = shk_params()
+        self._check(self.lib.shk_get_params(self._h, C.byref(p)))
+        return p
+
+    def set_params(self, **kw):
+        p = self.get_params()
+        for k, v in kw.items():
+            if not hasattr(p, k):
+                raise AttributeError(f"unknown parameter {k}")
+            setattr(p, k, v)
+        self._check(self.lib.shk_set_params(self._h, C.byref(p)))
+
+    def set_quadrature(self, xyw):
+        xyw = _f64(xyw)
+        self._check(self.lib.shk_set_quadrature(self._h, xyw.shape[0], _ptr(xyw)))
+
+    # --- fields
+    def set_field(self, name: str, values):
+        shape = (self.nv, 2) if name == "q" else (self.nv,)
+        a = _f64(values, shape)
+        self._check(self.lib.shk_set_field(self._h, FIELDS[name], _ptr(a)))
+
+    def get_field(self, name: str) -> np.ndarray:
+        out = np.empty((self.nv, 2) if name == "q" else (self.nv,), dtype=np.float64)
+        self._check(self.lib.shk_get_field(self._h, FIELDS[name], _ptr(out)))
+        return out
+
+    def set_dirichlet(self, dofs, value: float):
+        d = np.ascontiguousarray(dofs, dtype=np.int32)
+        self._check(self.lib.shk_set_dirichlet(self._h, d.size, _ptr(d), float(value)))
+
+    # --- hot path
+    def assemble(self, dt: float):
+        self._check(self.lib.shk_assemble(self._h, float(dt)))
+
+    def residual(self) -> np.ndarray:
+        out = np.empty(self.nv)
+        self._check(self.lib.shk_get_residual(self._h, _ptr(out)))
+        return out
+
+    @property
+    def nnz(self) -> int:
+        n = C.c_int64()
+        self._check(self.lib.shk_csr_nnz(self._h, C.byref(n)))
+        return n.value
+
+    def csr(self, values: bool = True):
+        nnz = self.nnz
+        rp = np.empty(self.nv + 1, dtype=np.int32)
+        ci = np.empty(nnz, dtype=np.int32)
+        va = np.empty(nnz) if values else None
+        self._check(self.lib.shk_get_csr(self._h, _ptr(rp), _ptr(ci), _ptr(va) if values else None))
+        return rp, ci, va
+
+    def linear_solve(self):
+        its, conv, rr = C.c_int32(), C.c_int32(), C.c_double()
+        self._check(self.lib.shk_linear_solve(self._h, C.byref(its), C.byref(conv), C.byref(rr)))
+        return its.value, bool(conv.value), rr.value
+
+    def spmv(self, x) -> np.ndarray:
+        x = _f64(x, (self.nv,))
+        y = np.empty(self.nv)
+        self._check(self.lib.shk_spmv(self._h, _ptr(x), _ptr(y)))
+        return y
+
+    def newton_solve(self, dt: float) -> shk_solve_info:
+        info = shk_solve_info()
+        self._check(self.lib.shk_newton_solve(self._h, float(dt), C.byref(info)))
+        return info
+
+    def update_explicit(self, dt: float):
+        self._check(self.lib.shk_update_explicit(self._h, float(dt)))
+
+    def step(self, dt: float) -> shk_solve_info:
+        info = shk_solve_info()
+        self._check(self.lib.shk_step(self._h, float(dt), C.byref(info)))
+        return info
+
+    def sync(self):
+        self._check(self.lib.shk_sync(self._h))
+
+    # --- measurement
+    def profile_enable(self, on: bool):
+        self._check(self.lib.shk_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self, reset: bool = True) -> dict:
+        p = shk_profile()
+        self._check(self.lib.shk_profile_read(self._h, C.byref(p), 1 if reset else 0))
+        return {name: dict(ms=p.ms[i], launches=p.launches[i]) for i, name in enumerate(PHASES)}
+
+    def time_kernel(self, phase: str, reps: int, dt: float = 3600.0) -> float:
+        ms = C.c_double()
+        self._check(self.lib.shk_time_kernel(self._h, PHASES.index(phase), reps, float(dt), C.byref(ms)))
+        return ms.value
+
+    def plan_stats(self) -> dict:
+        n = (C.c_int64 * 8)()
+        self._check(self.lib.shk_plan_stats(self._h, n))
+        keys = ("nv", "ne", "nnz", "asm_blocks", "asm_cells_computed", "spmv_blocks", "device_bytes", "max_row_len")
+        return dict(zip(keys, [int(v) for v in n]))

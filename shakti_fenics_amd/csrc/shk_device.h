@@ -1,0 +1,143 @@
+// Device-side argument blocks and the context layout shared by the kernels and the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/shakti_hip.h"
+#include "shk_plan.h"
+
+namespace shk {
+
+constexpr int kBlock = 256;        // threads per workgroup: 4 waves of 64
+constexpr int kMaxParts = 1024;    // upper bound of the reduction-partial arrays (= max grid)
+constexpr int kMaxQuad = 32;
+constexpr int kSpmvNnz = 2048;    // products one SpMV row block stages in LDS (16 KiB)
+
+// Constants of /root/reference/source/params.py:4-11 and derived products, passed by value
+// (kernarg segment -> scalar loads).
+struct DevParams {
+    double g, rho_i, rho_w, nu, Lh, omega, n, A, b_min;
+    double rwg;      // rho_w * g
+    double c_m;      // 1/rho_i - 1/rho_w
+    double kcoef;    // g / (12 nu)
+    double om_nu;    // omega / nu
+    double ri_rw;    // rho_i / rho_w
+    int n_is_3;
+};
+
+struct QuadArg {
+    int nq;
+    double phi0[kMaxQuad], phi1[kMaxQuad], phi2[kMaxQuad], w2[kMaxQuad];  // w2 = 2 * w
+};
+
+// Scalars of the BiCGStab recurrence.  Slots are written by block 0 of exactly one kernel and
+// read only by LATER kernels (visibility = kernel boundary on one stream).
+struct KrylovState {
+    double rho[2];      // (rhat, r) of iteration parity
+    double alpha;
+    double omega;
+    double target2;     // squared stopping threshold
+    double rnorm2;      // ||r||^2 at exit
+    double rhs2;        // ||rhs||^2
+    int done;           // 1 once converged / stopped; later kernels return immediately
+    int converged;
+    int breakdown;
+    int its;            // iterations completed when done was set
+};
+
+struct Mesh {  // device pointers
+    const double2* xy;
+    const int32_t* cells;  // 3*ne
+};
+
+struct AsmArgs {
+    Mesh m;
+    const double *N, *N_n, *b, *qx, *qy, *z_b, *z_s, *G, *melt_n, *storage, *inputs;
+    const uint8_t* bcflag;   // nullptr if no Dirichlet dofs
+    double bc_value;
+    double inv_rwg_dt;       // 1 / (rho_w g dt)
+    // plan
+    const int32_t *blk_row0, *blk_cellptr, *blk_cells, *incptr, *rowptr, *colidx;
+    const uint16_t* inccode;
+    int cells_max;           // LDS stride E
+    int rows_max;
+    int inc_max;
+    // outputs
+    double* F;
+    double* vals;
+    double* dinv;            // 1 / diag(J)
+    DevParams p;
+    QuadArg quad;
+};
+
+struct Ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int64_t nv = 0, ne = 0, nnz = 0;
+    shk_params params{};
+    DevParams dp{};
+    QuadArg quad{};
+    HostPlan plan;  // host copy kept for get_csr
+    int grid = 0;   // blocks used by grid-stride kernels == length of partial arrays
+    // device memory
+    std::vector<void*> allocs;
+    int64_t device_bytes = 0;
+    double2* d_xy = nullptr;
+    int32_t* d_cells = nullptr;
+    double* f[SHK_FIELD_COUNT] = {nullptr};  // SHK_Q slot unused (qx/qy are separate)
+    double *d_melt_tmp = nullptr, *d_b_tmp = nullptr, *d_m0 = nullptr;
+    uint8_t* d_bcflag = nullptr;
+    bool has_bc = false;
+    double bc_value = 0.0;
+    int32_t *d_rowptr = nullptr, *d_colidx = nullptr, *d_diagpos = nullptr, *d_lastcell = nullptr;
+    int32_t *d_blk_row0 = nullptr, *d_blk_cellptr = nullptr, *d_blk_cells = nullptr, *d_incptr = nullptr;
+    uint16_t* d_inccode = nullptr;
+    int32_t* d_sp_row0 = nullptr;
+    int nblk = 0, nsb = 0;
+    size_t asm_lds = 0;
+    double *d_F = nullptr, *d_vals = nullptr, *d_vals_s = nullptr, *d_dinv = nullptr;
+    // Krylov vectors
+    double *d_r = nullptr, *d_rhat = nullptr, *d_p = nullptr, *d_v = nullptr, *d_s = nullptr, *d_t = nullptr,
+           *d_y = nullptr;
+    double* d_part = nullptr;  // 6 arrays of kMaxParts
+    KrylovState* d_state = nullptr;
+    KrylovState* h_state = nullptr;  // pinned, 2 slots
+    double* h_part = nullptr;        // pinned, kMaxParts
+    bool assembled = false;
+    double assembled_dt = 0.0;
+    // profiling
+    bool profiling = false;
+    struct Ev { hipEvent_t a, b; int phase; };
+    std::vector<Ev> ev_pool;
+    size_t ev_used = 0;
+    shk_profile prof{};
+};
+
+// partial-array slots
+enum { P_RHO = 0, P_RR = 1, P_RHV = 2, P_TS = 3, P_TT = 4, P_AUX = 5 };
+
+// launchers (shk_kernels.hip)
+hipError_t prepare_kernels(Ctx* c);
+void launch_assemble(Ctx* c, double dt);
+void launch_assemble_impl(Ctx* c, double dt, bool with_j);
+void launch_scale(Ctx* c);
+void launch_spmv_plain(Ctx* c, const double* vals, const double* x, double* y);
+void launch_norm2(Ctx* c, const double* x, double* partials);
+void krylov_init(Ctx* c);
+void krylov_iteration(Ctx* c, int it);
+void launch_newton_update(Ctx* c, bool apply);
+void launch_update_explicit(Ctx* c, double dt);
+void launch_split_q(Ctx* c, const double* q_interleaved);
+void launch_join_q(Ctx* c, double* q_interleaved);
+
+struct PhaseTimer {  // RAII hipEvent pair when profiling is on
+    Ctx* c;
+    int idx = -1;
+    PhaseTimer(Ctx* c, int phase);
+    ~PhaseTimer();
+};
+
+}  // namespace shk

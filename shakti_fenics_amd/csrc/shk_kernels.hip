@@ -1,0 +1,648 @@
+// gfx950 kernels of the SHAKTI hot path.  All arithmetic is fp64 vector (no MFMA: the path is
+// sparse and bandwidth-bound).  Wave = 64 lanes, workgroup = 256 threads throughout.
+//
+//   k_assemble      R1+R2+R3  residual + CSR Jacobian of the weak form at
+//                             /root/reference/source/solvers.py:35-45 (closures constitutive.py:6-31),
+//                             atomic-free: each workgroup owns a row range, stages the element tensors
+//                             of every cell touching those rows in LDS, then writes each CSR value and
+//                             residual entry exactly once (deterministic summation order).
+//   k_spmv          CSR-stream SpMV with the BiCGStab dot products fused into the row epilogue.
+//   k_bicg_*        fused vector updates of right-Jacobi-preconditioned BiCGStab; scalars are
+//                   re-derived in every workgroup from per-workgroup partial sums, so there is no
+//                   host sync, no atomics, and results are bitwise reproducible.
+//   k_update_a/b    R6+R7 and R8 (+clamp, + N_n <- N): solvers.py:186-197,228.
+#include "shk_device.h"
+
+namespace shk {
+
+// ------------------------------------------------------------------ reductions
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;  // valid in lane 0
+}
+
+// Sum over the 256 threads of the workgroup; every thread returns the same value.
+__device__ __forceinline__ double block_sum(double v, double* sh4) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();  // protect sh4 against a previous use
+    if (lane == 0) sh4[w] = v;
+    __syncthreads();
+    return (sh4[0] + sh4[1]) + (sh4[2] + sh4[3]);
+}
+
+// Fixed-order sum of a partial array (identical in every workgroup and every run).
+__device__ __forceinline__ double reduce_partials(const double* __restrict__ P, int n, double* sh4) {
+    double a = 0.0;
+    for (int i = threadIdx.x; i < n; i += kBlock) a += P[i];
+    return block_sum(a, sh4);
+}
+
+__device__ __forceinline__ double glen_pow(double N, const DevParams& p) {
+    // |N|^(n-1), constitutive.py:31; n = 3 (params.py:10) is the square
+    return p.n_is_3 ? N * N : pow(fabs(N), p.n - 1.0);
+}
+
+// ------------------------------------------------------------------ assembly
+template <bool WITH_J>
+__global__ __launch_bounds__(kBlock) void k_assemble(const AsmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int E = a.cells_max;
+    double* et = reinterpret_cast<double*>(smem);                 // [12][E] element tensors
+    int* cv = reinterpret_cast<int*>(et + 12 * (size_t)E);       // [3][E] cell vertex ids
+    int* rp = cv + 3 * E;                                         // [rows_max+1] rowptr of owned rows
+    int* ip = rp + (a.rows_max + 1);                              // [rows_max+1] incptr of owned rows
+    uint16_t* ic = reinterpret_cast<uint16_t*>(ip + (a.rows_max + 1));  // incidence codes
+
+    const int blk = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int r0 = a.blk_row0[blk], r1 = a.blk_row0[blk + 1];
+    const int nrows = r1 - r0;
+    const int c0 = a.blk_cellptr[blk], ncell = a.blk_cellptr[blk + 1] - c0;
+    const DevParams& p = a.p;
+
+    for (int i = tid; i <= nrows; i += kBlock) {
+        rp[i] = a.rowptr[r0 + i];
+        ip[i] = a.incptr[r0 + i];
+    }
+    const int ip0 = a.incptr[r0], ninc = a.incptr[r1] - ip0;
+    for (int i = tid; i < ninc; i += kBlock) ic[i] = a.inccode[ip0 + i];
+
+    // ---- phase 1: one thread per cell touching the owned rows ----
+    for (int t = tid; t < ncell; t += kBlock) {
+        const int c = a.blk_cells[c0 + t];
+        const int v0 = a.m.cells[3 * (size_t)c + 0], v1 = a.m.cells[3 * (size_t)c + 1],
+                  v2 = a.m.cells[3 * (size_t)c + 2];
+        cv[t] = v0; cv[E + t] = v1; cv[2 * E + t] = v2;
+        const double2 p0 = a.m.xy[v0], p1 = a.m.xy[v1], p2 = a.m.xy[v2];
+        const double d1x = p1.x - p0.x, d1y = p1.y - p0.y, d2x = p2.x - p0.x, d2y = p2.y - p0.y;
+        const double det = d1x * d2y - d1y * d2x;
+        const double inv = 1.0 / det;
+        const double area = 0.5 * fabs(det);
+        const double g1x = d2y * inv, g1y = -d2x * inv, g2x = -d1y * inv, g2y = d1x * inv;
+        const double g0x = -(g1x + g2x), g0y = -(g1y + g2y);
+
+        const double N0 = a.N[v0], N1 = a.N[v1], N2 = a.N[v2];
+        const double b0 = a.b[v0], b1 = a.b[v1], b2 = a.b[v2];
+        const double m0_ = a.melt_n[v0], m1_ = a.melt_n[v1], m2_ = a.melt_n[v2];
+        // Head, constitutive.py:6-9
+        double h0, h1, h2;
+        {
+            const double zb0 = a.z_b[v0], zb1 = a.z_b[v1], zb2 = a.z_b[v2];
+            const double zs0 = a.z_s[v0], zs1 = a.z_s[v1], zs2 = a.z_s[v2];
+            h0 = zb0 + p.ri_rw * (zs0 - zb0) - N0 / p.rwg;
+            h1 = zb1 + p.ri_rw * (zs1 - zb1) - N1 / p.rwg;
+            h2 = zb2 + p.ri_rw * (zs2 - zb2) - N2 / p.rwg;
+        }
+        const double ghx = h0 * g0x + h1 * g1x + h2 * g2x, ghy = h0 * g0y + h1 * g1y + h2 * g2y;
+        const double gbx = b0 * g0x + b1 * g1x + b2 * g2x, gby = b0 * g0y + b1 * g1y + b2 * g2y;
+        const double gmx = m0_ * g0x + m1_ * g1x + m2_ * g2x, gmy = m0_ * g0y + m1_ * g1y + m2_ * g2y;
+        const double gb2 = gbx * gbx + gby * gby;
+        const double den_b = 1.0 + gb2;
+        const double gmgb = gmx * gbx + gmy * gby;
+
+        const double Nn0 = a.N_n[v0], Nn1 = a.N_n[v1], Nn2 = a.N_n[v2];
+        const double qx0 = a.qx[v0], qx1 = a.qx[v1], qx2 = a.qx[v2];
+        const double qy0 = a.qy[v0], qy1 = a.qy[v1], qy2 = a.qy[v2];
+        const double G0 = a.G[v0], G1 = a.G[v1], G2 = a.G[v2];
+        const double s0 = a.storage[v0], s1 = a.storage[v1], s2 = a.storage[v2];
+        const double i0 = a.inputs[v0], i1 = a.inputs[v1], i2 = a.inputs[v2];
+
+        double sK = 0.0, F0 = 0.0, F1 = 0.0, F2 = 0.0;
+        double T00 = 0.0, T01 = 0.0, T02 = 0.0, T11 = 0.0, T12 = 0.0, T22 = 0.0;
+        for (int k = 0; k < a.quad.nq; ++k) {
+            const double f0 = a.quad.phi0[k], f1 = a.quad.phi1[k], f2 = a.quad.phi2[k];
+            const double w = a.quad.w2[k] * area;
+            const double Nk = N0 * f0 + N1 * f1 + N2 * f2;
+            const double Nnk = Nn0 * f0 + Nn1 * f1 + Nn2 * f2;
+            const double bk = b0 * f0 + b1 * f1 + b2 * f2;
+            const double qxk = qx0 * f0 + qx1 * f1 + qx2 * f2;
+            const double qyk = qy0 * f0 + qy1 * f1 + qy2 * f2;
+            const double Gk = G0 * f0 + G1 * f1 + G2 * f2;
+            const double mk = m0_ * f0 + m1_ * f1 + m2_ * f2;
+            const double sk = s0 * f0 + s1 * f1 + s2 * f2;
+            const double ik = i0 * f0 + i1 * f1 + i2 * f2;
+            // WaterFlux with the Reynolds switch, constitutive.py:11-20: q_w = -K grad(h)
+            const double qn = sqrt(qxk * qxk + qyk * qyk);
+            const double ab = fabs(bk);
+            const double K = ab * ab * ab * p.kcoef / (1.0 + p.om_nu * qn);
+            // Melt, constitutive.py:22-27 (div of the cell-wise P1 product expanded)
+            const double melt0 = (Gk - p.rwg * (qxk * ghx + qyk * ghy)) / p.Lh;
+            const double mdiff = (mk * gb2 + bk * gmgb) / den_b;
+            const double pw = glen_pow(Nk, p);
+            const double closure = p.A * bk * Nk * pw;                 // constitutive.py:29-31
+            const double stor = sk * (Nk - Nnk) * a.inv_rwg_dt;        // solvers.py:42
+            const double src = p.c_m * (melt0 + mdiff) - closure - stor - ik;
+            sK += w * K;
+            const double ws = w * src;
+            F0 += ws * f0; F1 += ws * f1; F2 += ws * f2;
+            if (WITH_J) {
+                const double wd = w * (p.A * p.n * bk * pw + sk * a.inv_rwg_dt);
+                T00 += wd * f0 * f0; T01 += wd * f0 * f1; T02 += wd * f0 * f2;
+                T11 += wd * f1 * f1; T12 += wd * f1 * f2; T22 += wd * f2 * f2;
+            }
+        }
+        // flux term: K grad(h).grad(phi_i)
+        double Fe0 = sK * (ghx * g0x + ghy * g0y) + F0;
+        double Fe1 = sK * (ghx * g1x + ghy * g1y) + F1;
+        double Fe2 = sK * (ghx * g2x + ghy * g2y) + F2;
+        double K00 = 0, K01 = 0, K02 = 0, K10 = 0, K11 = 0, K12 = 0, K20 = 0, K21 = 0, K22 = 0;
+        const bool anybc = a.bcflag && (a.bcflag[v0] | a.bcflag[v1] | a.bcflag[v2]);
+        if (WITH_J || anybc) {
+            const double kk = -sK / p.rwg;
+            const double d00 = g0x * g0x + g0y * g0y, d01 = g0x * g1x + g0y * g1y, d02 = g0x * g2x + g0y * g2y;
+            const double d11 = g1x * g1x + g1y * g1y, d12 = g1x * g2x + g1y * g2y, d22 = g2x * g2x + g2y * g2y;
+            // int phi_i q_x dx = area/12 (sum q_x + q_x,i): exact P1 mass matrix
+            const double cq = p.c_m / p.Lh * area * (1.0 / 12.0);
+            const double sx = qx0 + qx1 + qx2, sy = qy0 + qy1 + qy2;
+            const double Px0 = cq * (sx + qx0), Px1 = cq * (sx + qx1), Px2 = cq * (sx + qx2);
+            const double Py0 = cq * (sy + qy0), Py1 = cq * (sy + qy1), Py2 = cq * (sy + qy2);
+            if (!WITH_J) {
+                // residual-only pass still needs K_ij of BC columns for the lifting term
+                for (int k = 0; k < a.quad.nq; ++k) {
+                    const double f0 = a.quad.phi0[k], f1 = a.quad.phi1[k], f2 = a.quad.phi2[k];
+                    const double w = a.quad.w2[k] * area;
+                    const double Nk = N0 * f0 + N1 * f1 + N2 * f2;
+                    const double bk = b0 * f0 + b1 * f1 + b2 * f2;
+                    const double sk = s0 * f0 + s1 * f1 + s2 * f2;
+                    const double wd = w * (p.A * p.n * bk * glen_pow(Nk, p) + sk * a.inv_rwg_dt);
+                    T00 += wd * f0 * f0; T01 += wd * f0 * f1; T02 += wd * f0 * f2;
+                    T11 += wd * f1 * f1; T12 += wd * f1 * f2; T22 += wd * f2 * f2;
+                }
+            }
+            K00 = kk * d00 + (Px0 * g0x + Py0 * g0y) - T00;
+            K01 = kk * d01 + (Px0 * g1x + Py0 * g1y) - T01;
+            K02 = kk * d02 + (Px0 * g2x + Py0 * g2y) - T02;
+            K10 = kk * d01 + (Px1 * g0x + Py1 * g0y) - T01;
+            K11 = kk * d11 + (Px1 * g1x + Py1 * g1y) - T11;
+            K12 = kk * d12 + (Px1 * g2x + Py1 * g2y) - T12;
+            K20 = kk * d02 + (Px2 * g0x + Py2 * g0y) - T02;
+            K21 = kk * d12 + (Px2 * g1x + Py2 * g1y) - T12;
+            K22 = kk * d22 + (Px2 * g2x + Py2 * g2y) - T22;
+            if (anybc) {
+                // apply_lifting(alpha=-1): F_i += K_ij (g - N_j) over Dirichlet columns j
+                const double l0 = a.bcflag[v0] ? a.bc_value - N0 : 0.0;
+                const double l1 = a.bcflag[v1] ? a.bc_value - N1 : 0.0;
+                const double l2 = a.bcflag[v2] ? a.bc_value - N2 : 0.0;
+                Fe0 += K00 * l0 + K01 * l1 + K02 * l2;
+                Fe1 += K10 * l0 + K11 * l1 + K12 * l2;
+                Fe2 += K20 * l0 + K21 * l1 + K22 * l2;
+            }
+        }
+        if (WITH_J) {
+            et[0 * E + t] = K00; et[1 * E + t] = K01; et[2 * E + t] = K02;
+            et[3 * E + t] = K10; et[4 * E + t] = K11; et[5 * E + t] = K12;
+            et[6 * E + t] = K20; et[7 * E + t] = K21; et[8 * E + t] = K22;
+        }
+        et[9 * E + t] = Fe0; et[10 * E + t] = Fe1; et[11 * E + t] = Fe2;
+    }
+    __syncthreads();
+
+    // ---- phase 2a: one thread per stored Jacobian entry of the owned rows ----
+    if (WITH_J) {
+        const int n0 = rp[0], n1 = rp[nrows];
+        for (int s = n0 + tid; s < n1; s += kBlock) {
+            int lo = 0, hi = nrows;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (rp[mid] <= s) lo = mid; else hi = mid;
+            }
+            const int v = r0 + lo;
+            const int u = a.colidx[s];
+            double sum = 0.0;
+            const int kb = ip[lo] - ip0, ke = ip[lo + 1] - ip0;
+            for (int k = kb; k < ke; ++k) {  // ascending cell id: fixed summation order
+                const int code = ic[k];
+                const int t = code >> 2, li = code & 3;
+                const int j = (cv[t] == u) ? 0 : (cv[E + t] == u) ? 1 : (cv[2 * E + t] == u) ? 2 : -1;
+                if (j >= 0) sum += et[(li * 3 + j) * E + t];
+            }
+            if (a.bcflag) {  // Dirichlet rows and columns zeroed, unit diagonal
+                const bool bv = a.bcflag[v], bu = a.bcflag[u];
+                if (bv | bu) sum = (u == v && bv) ? 1.0 : 0.0;
+            }
+            a.vals[s] = sum;
+            if (u == v) a.dinv[v] = (sum != 0.0) ? 1.0 / sum : 1.0;
+        }
+    }
+    // ---- phase 2b: one thread per owned residual row ----
+    for (int i = tid; i < nrows; i += kBlock) {
+        const int v = r0 + i;
+        double sum = 0.0;
+        const int kb = ip[i] - ip0, ke = ip[i + 1] - ip0;
+        for (int k = kb; k < ke; ++k) {
+            const int code = ic[k];
+            sum += et[(9 + (code & 3)) * E + (code >> 2)];
+        }
+        if (a.bcflag && a.bcflag[v]) sum = a.N[v] - a.bc_value;  // set_bc(b, bcs, x, -1)
+        a.F[v] = sum;
+    }
+}
+
+void launch_assemble_impl(Ctx* c, double dt, bool with_j) {
+    AsmArgs a;
+    a.m.xy = c->d_xy;
+    a.m.cells = c->d_cells;
+    a.N = c->f[SHK_N]; a.N_n = c->f[SHK_N_N]; a.b = c->f[SHK_B]; a.qx = c->f[SHK_QX]; a.qy = c->f[SHK_QY];
+    a.z_b = c->f[SHK_Z_B]; a.z_s = c->f[SHK_Z_S]; a.G = c->f[SHK_G]; a.melt_n = c->f[SHK_MELT_N];
+    a.storage = c->f[SHK_STORAGE]; a.inputs = c->f[SHK_INPUTS];
+    a.bcflag = c->has_bc ? c->d_bcflag : nullptr;
+    a.bc_value = c->bc_value;
+    a.inv_rwg_dt = 1.0 / (c->dp.rwg * dt);
+    a.blk_row0 = c->d_blk_row0; a.blk_cellptr = c->d_blk_cellptr; a.blk_cells = c->d_blk_cells;
+    a.incptr = c->d_incptr; a.rowptr = c->d_rowptr; a.colidx = c->d_colidx; a.inccode = c->d_inccode;
+    a.cells_max = c->plan.cells_max; a.rows_max = c->plan.rows_max; a.inc_max = c->plan.max_inc_per_block;
+    a.F = c->d_F; a.vals = c->d_vals; a.dinv = c->d_dinv;
+    a.p = c->dp;
+    a.quad = c->quad;
+    PhaseTimer t(c, SHK_PH_ASSEMBLE);
+    if (with_j)
+        hipLaunchKernelGGL(k_assemble<true>, dim3(c->nblk), dim3(kBlock), c->asm_lds, c->stream, a);
+    else
+        hipLaunchKernelGGL(k_assemble<false>, dim3(c->nblk), dim3(kBlock), c->asm_lds, c->stream, a);
+}
+
+void launch_assemble(Ctx* c, double dt) { launch_assemble_impl(c, dt, true); }
+
+// Dynamic LDS above 64 KiB has to be requested per kernel.
+hipError_t prepare_kernels(Ctx* c) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->asm_lds);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble<false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->asm_lds);
+}
+
+// A' = A D^-1 (right Jacobi preconditioning folded into the matrix once per Newton iteration)
+__global__ __launch_bounds__(kBlock) void k_scale(int64_t nnz, const int32_t* __restrict__ colidx,
+                                                  const double* __restrict__ vals,
+                                                  const double* __restrict__ dinv, double* __restrict__ out) {
+    for (int64_t s = blockIdx.x * (int64_t)kBlock + threadIdx.x; s < nnz; s += (int64_t)gridDim.x * kBlock)
+        out[s] = vals[s] * dinv[colidx[s]];
+}
+
+void launch_scale(Ctx* c) {
+    PhaseTimer t(c, SHK_PH_OTHER);
+    int g = (int)std::min<int64_t>((c->nnz + kBlock - 1) / kBlock, 8192);
+    hipLaunchKernelGGL(k_scale, dim3(g), dim3(kBlock), 0, c->stream, c->nnz, c->d_colidx, c->d_vals, c->d_dinv,
+                       c->d_vals_s);
+}
+
+// ------------------------------------------------------------------ SpMV (CSR-stream)
+// MODE 0: y = A x.   MODE 1: + partial (w . y) -> pa.   MODE 2: + partials (y . x_own) -> pa, (y . y) -> pb.
+template <int MODE, int NNZB>
+__global__ __launch_bounds__(kBlock) void k_spmv(const int32_t* __restrict__ sp_row0, int nsb,
+                                                 const int32_t* __restrict__ rowptr,
+                                                 const int32_t* __restrict__ colidx,
+                                                 const double* __restrict__ vals, const double* __restrict__ x,
+                                                 double* __restrict__ y, const double* __restrict__ w,
+                                                 double* __restrict__ pa, double* __restrict__ pb,
+                                                 const KrylovState* __restrict__ st) {
+    __shared__ double prod[NNZB];
+    __shared__ double sh4[4];
+    if (MODE != 0 && st->done) return;
+    const int tid = threadIdx.x;
+    double da = 0.0, db = 0.0;
+    for (int sb = blockIdx.x; sb < nsb; sb += gridDim.x) {
+        const int r0 = sp_row0[sb], r1 = sp_row0[sb + 1];
+        const int n0 = rowptr[r0], n1 = rowptr[r1];
+        for (int s = n0 + tid; s < n1; s += kBlock) prod[s - n0] = vals[s] * x[colidx[s]];
+        __syncthreads();
+        for (int r = r0 + tid; r < r1; r += kBlock) {
+            const int a = rowptr[r] - n0, b = rowptr[r + 1] - n0;
+            double sum = 0.0;
+            for (int k = a; k < b; ++k) sum += prod[k];
+            y[r] = sum;
+            if (MODE == 1) da += w[r] * sum;
+            if (MODE == 2) { da += sum * x[r]; db += sum * sum; }
+        }
+        __syncthreads();
+    }
+    if (MODE >= 1) {
+        const double ra = block_sum(da, sh4);
+        if (tid == 0) pa[blockIdx.x] = ra;
+    }
+    if (MODE == 2) {
+        const double rb = block_sum(db, sh4);
+        if (tid == 0) pb[blockIdx.x] = rb;
+    }
+}
+
+void launch_spmv_plain(Ctx* c, const double* vals, const double* x, double* y) {
+    PhaseTimer t(c, SHK_PH_SPMV);
+    hipLaunchKernelGGL((k_spmv<0, kSpmvNnz>), dim3(c->grid), dim3(kBlock), 0, c->stream, c->d_sp_row0, c->nsb,
+                       c->d_rowptr, c->d_colidx, vals, x, y, nullptr, nullptr, nullptr, c->d_state);
+}
+
+// ------------------------------------------------------------------ vector kernels
+__global__ __launch_bounds__(kBlock) void k_norm2(int64_t n, const double* __restrict__ x, double* __restrict__ part) {
+    __shared__ double sh4[4];
+    double a = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        a += x[i] * x[i];
+    a = block_sum(a, sh4);
+    if (threadIdx.x == 0) part[blockIdx.x] = a;
+}
+
+void launch_norm2(Ctx* c, const double* x, double* partials) {
+    PhaseTimer t(c, SHK_PH_OTHER);
+    hipLaunchKernelGGL(k_norm2, dim3(c->grid), dim3(kBlock), 0, c->stream, c->nv, x, partials);
+}
+
+// r = rhat = rhs, p = v = y = 0, partials of ||rhs||^2; block 0 resets the recurrence scalars.
+__global__ __launch_bounds__(kBlock) void k_bicg_init(int64_t n, const double* __restrict__ rhs,
+                                                      double* __restrict__ r, double* __restrict__ rhat,
+                                                      double* __restrict__ p, double* __restrict__ v,
+                                                      double* __restrict__ y, double* __restrict__ part,
+                                                      KrylovState* __restrict__ st) {
+    __shared__ double sh4[4];
+    double a = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const double f = rhs[i];
+        r[i] = f; rhat[i] = f; p[i] = 0.0; v[i] = 0.0; y[i] = 0.0;
+        a += f * f;
+    }
+    a = block_sum(a, sh4);
+    if (threadIdx.x == 0) {
+        part[P_RHO * kMaxParts + blockIdx.x] = a;
+        part[P_RR * kMaxParts + blockIdx.x] = a;
+        if (blockIdx.x == 0) {
+            st->rho[0] = 1.0; st->rho[1] = 1.0; st->alpha = 1.0; st->omega = 1.0;
+            st->target2 = 0.0; st->rnorm2 = 0.0; st->rhs2 = 0.0;
+            st->done = 0; st->converged = 0; st->breakdown = 0; st->its = 0;
+        }
+    }
+}
+
+// Start of iteration `it`: convergence test on ||r||, then p = r + beta (p - omega v).
+__global__ __launch_bounds__(kBlock) void k_bicg_p(int64_t n, int it, int max_it, double rtol2, double atol2,
+                                                   int np, const double* __restrict__ part,
+                                                   const double* __restrict__ r, const double* __restrict__ v,
+                                                   double* __restrict__ p, KrylovState* __restrict__ st) {
+    __shared__ double sh4[4];
+    if (st->done) return;
+    const double rho_new = reduce_partials(part + P_RHO * kMaxParts, np, sh4);
+    const double rr = reduce_partials(part + P_RR * kMaxParts, np, sh4);
+    const double target2 = (it == 0) ? fmax(rtol2 * rr, atol2) : st->target2;
+    const double rho_old = st->rho[(it + 1) & 1], alpha = st->alpha, omega = st->omega;
+    const double beta = (rho_new / rho_old) * (alpha / omega);
+    const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
+    int stop = 0, conv = 0, brk = 0;
+    if (!(rr > target2)) { stop = 1; conv = (rr <= target2); }   // also stops on NaN
+    else if (it >= max_it) stop = 1;
+    else if (!isfinite(beta)) { stop = 1; brk = 1; }
+    if (stop) {
+        if (lead) {
+            st->converged = conv; st->breakdown = brk; st->its = it; st->rnorm2 = rr;
+            if (it == 0) { st->target2 = target2; st->rhs2 = rr; }
+            st->done = 1;
+        }
+        return;
+    }
+    if (lead) {
+        st->rho[it & 1] = rho_new;
+        if (it == 0) { st->target2 = target2; st->rhs2 = rr; }
+    }
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        p[i] = r[i] + beta * (p[i] - omega * v[i]);
+}
+
+// alpha = rho / (rhat . v); s = r - alpha v
+__global__ __launch_bounds__(kBlock) void k_bicg_s(int64_t n, int it, int np, const double* __restrict__ part,
+                                                   const double* __restrict__ r, const double* __restrict__ v,
+                                                   double* __restrict__ s, KrylovState* __restrict__ st) {
+    __shared__ double sh4[4];
+    if (st->done) return;
+    const double rhv = reduce_partials(part + P_RHV * kMaxParts, np, sh4);
+    const double alpha = st->rho[it & 1] / rhv;
+    const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
+    if (!isfinite(alpha)) {
+        if (lead) { st->breakdown = 1; st->converged = 0; st->its = it; st->done = 1; }
+        return;
+    }
+    if (lead) st->alpha = alpha;
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        s[i] = r[i] - alpha * v[i];
+}
+
+// omega = (t.s)/(t.t); y += alpha p + omega s; r = s - omega t; partials (rhat.r), (r.r)
+__global__ __launch_bounds__(kBlock) void k_bicg_xr(int64_t n, int np, double* __restrict__ part,
+                                                    const double* __restrict__ p, const double* __restrict__ s,
+                                                    const double* __restrict__ t, const double* __restrict__ rhat,
+                                                    double* __restrict__ y, double* __restrict__ r,
+                                                    KrylovState* __restrict__ st) {
+    __shared__ double sh4[4];
+    if (st->done) return;
+    const double ts = reduce_partials(part + P_TS * kMaxParts, np, sh4);
+    const double tt = reduce_partials(part + P_TT * kMaxParts, np, sh4);
+    const double omega = (tt > 0.0) ? ts / tt : 0.0;
+    const double alpha = st->alpha;
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->omega = omega;
+    double a = 0.0, b = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const double si = s[i];
+        y[i] += alpha * p[i] + omega * si;
+        const double ri = si - omega * t[i];
+        r[i] = ri;
+        a += rhat[i] * ri;
+        b += ri * ri;
+    }
+    a = block_sum(a, sh4);
+    b = block_sum(b, sh4);
+    if (threadIdx.x == 0) {
+        part[P_RHO * kMaxParts + blockIdx.x] = a;
+        part[P_RR * kMaxParts + blockIdx.x] = b;
+    }
+}
+
+void krylov_init(Ctx* c) {
+    PhaseTimer t(c, SHK_PH_VECTOR);
+    hipLaunchKernelGGL(k_bicg_init, dim3(c->grid), dim3(kBlock), 0, c->stream, c->nv, c->d_F, c->d_r, c->d_rhat,
+                       c->d_p, c->d_v, c->d_y, c->d_part, c->d_state);
+}
+
+void krylov_iteration(Ctx* c, int it) {
+    const dim3 g(c->grid), b(kBlock);
+    const double rt = c->params.krylov_rtol, at = c->params.krylov_atol;
+    double* part = c->d_part;
+    {
+        PhaseTimer t(c, SHK_PH_VECTOR);
+        hipLaunchKernelGGL(k_bicg_p, g, b, 0, c->stream, c->nv, it, c->params.krylov_max_it, rt * rt, at * at,
+                           c->grid, part, c->d_r, c->d_v, c->d_p, c->d_state);
+    }
+    {
+        PhaseTimer t(c, SHK_PH_SPMV);
+        hipLaunchKernelGGL((k_spmv<1, kSpmvNnz>), g, b, 0, c->stream, c->d_sp_row0, c->nsb, c->d_rowptr,
+                           c->d_colidx, c->d_vals_s, c->d_p, c->d_v, c->d_rhat, part + P_RHV * kMaxParts, nullptr,
+                           c->d_state);
+    }
+    {
+        PhaseTimer t(c, SHK_PH_VECTOR);
+        hipLaunchKernelGGL(k_bicg_s, g, b, 0, c->stream, c->nv, it, c->grid, part, c->d_r, c->d_v, c->d_s,
+                           c->d_state);
+    }
+    {
+        PhaseTimer t(c, SHK_PH_SPMV);
+        hipLaunchKernelGGL((k_spmv<2, kSpmvNnz>), g, b, 0, c->stream, c->d_sp_row0, c->nsb, c->d_rowptr,
+                           c->d_colidx, c->d_vals_s, c->d_s, c->d_t, nullptr, part + P_TS * kMaxParts,
+                           part + P_TT * kMaxParts, c->d_state);
+    }
+    {
+        PhaseTimer t(c, SHK_PH_VECTOR);
+        hipLaunchKernelGGL(k_bicg_xr, g, b, 0, c->stream, c->nv, c->grid, part, c->d_p, c->d_s, c->d_t, c->d_rhat,
+                           c->d_y, c->d_r, c->d_state);
+    }
+}
+
+// dx = D^-1 y (undo the right preconditioning); N <- N - relax dx   (NewtonSolver update)
+__global__ __launch_bounds__(kBlock) void k_newton_update(int64_t n, double relax, int apply,
+                                                          const double* __restrict__ y,
+                                                          const double* __restrict__ dinv, double* __restrict__ dx,
+                                                          double* __restrict__ N) {
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const double d = y[i] * dinv[i];
+        dx[i] = d;
+        if (apply) N[i] -= relax * d;
+    }
+}
+
+void launch_newton_update(Ctx* c, bool apply) {
+    PhaseTimer t(c, SHK_PH_OTHER);
+    hipLaunchKernelGGL(k_newton_update, dim3(c->grid), dim3(kBlock), 0, c->stream, c->nv, c->params.newton_relax,
+                       apply ? 1 : 0, c->d_y, c->d_dinv, c->f[SHK_DX], c->f[SHK_N]);
+}
+
+// ------------------------------------------------------------------ explicit updates (R6-R8)
+struct UpdArgs {
+    Mesh m;
+    const int32_t* lastcell;
+    const double *N, *z_b, *z_s, *G;
+    double *b, *qx, *qy, *melt_n, *N_n;
+    double *melt_tmp, *b_tmp, *m0;
+    double dt;
+    int64_t nv;
+    DevParams p;
+};
+
+struct CellGeom { int v0, v1, v2; double g0x, g0y, g1x, g1y, g2x, g2y; };
+
+__device__ __forceinline__ CellGeom cell_geom(const Mesh& m, int c) {
+    CellGeom g;
+    g.v0 = m.cells[3 * (size_t)c]; g.v1 = m.cells[3 * (size_t)c + 1]; g.v2 = m.cells[3 * (size_t)c + 2];
+    const double2 p0 = m.xy[g.v0], p1 = m.xy[g.v1], p2 = m.xy[g.v2];
+    const double d1x = p1.x - p0.x, d1y = p1.y - p0.y, d2x = p2.x - p0.x, d2y = p2.y - p0.y;
+    const double inv = 1.0 / (d1x * d2y - d1y * d2x);
+    g.g1x = d2y * inv; g.g1y = -d2x * inv; g.g2x = -d1y * inv; g.g2y = d1x * inv;
+    g.g0x = -(g.g1x + g.g2x); g.g0y = -(g.g1y + g.g2y);
+    return g;
+}
+
+// q <- WaterFlux(b, Head(N), Reynolds(q_old)) and melt_n <- Melt(q_new, ., ., b, melt_old) at each vertex,
+// gradients taken on T*(v) = highest cell containing v (solvers.py:186,189).
+__global__ __launch_bounds__(kBlock) void k_update_a(const UpdArgs a) {
+    const DevParams& p = a.p;
+    for (int64_t v = blockIdx.x * (int64_t)kBlock + threadIdx.x; v < a.nv; v += (int64_t)gridDim.x * kBlock) {
+        const CellGeom g = cell_geom(a.m, a.lastcell[v]);
+        const double h0 = a.z_b[g.v0] + p.ri_rw * (a.z_s[g.v0] - a.z_b[g.v0]) - a.N[g.v0] / p.rwg;
+        const double h1 = a.z_b[g.v1] + p.ri_rw * (a.z_s[g.v1] - a.z_b[g.v1]) - a.N[g.v1] / p.rwg;
+        const double h2 = a.z_b[g.v2] + p.ri_rw * (a.z_s[g.v2] - a.z_b[g.v2]) - a.N[g.v2] / p.rwg;
+        const double ghx = h0 * g.g0x + h1 * g.g1x + h2 * g.g2x, ghy = h0 * g.g0y + h1 * g.g1y + h2 * g.g2y;
+        const double b0 = a.b[g.v0], b1 = a.b[g.v1], b2 = a.b[g.v2];
+        const double gbx = b0 * g.g0x + b1 * g.g1x + b2 * g.g2x, gby = b0 * g.g0y + b1 * g.g1y + b2 * g.g2y;
+        const double m0_ = a.melt_n[g.v0], m1_ = a.melt_n[g.v1], m2_ = a.melt_n[g.v2];
+        const double gmx = m0_ * g.g0x + m1_ * g.g1x + m2_ * g.g2x, gmy = m0_ * g.g0y + m1_ * g.g1y + m2_ * g.g2y;
+        const double bv = a.b[v], mv = a.melt_n[v];
+        const double qxo = a.qx[v], qyo = a.qy[v];
+        const double qn = sqrt(qxo * qxo + qyo * qyo);
+        const double ab = fabs(bv);
+        const double K = ab * ab * ab * p.kcoef / (1.0 + p.om_nu * qn);
+        const double qxn = -K * ghx, qyn = -K * ghy;
+        const double melt0 = (a.G[v] - p.rwg * (qxn * ghx + qyn * ghy)) / p.Lh;
+        const double gb2 = gbx * gbx + gby * gby;
+        const double meltn = melt0 + (mv * gb2 + bv * (gmx * gbx + gmy * gby)) / (1.0 + gb2);
+        a.qx[v] = qxn; a.qy[v] = qyn;   // depends on q_old of this vertex only: in place is safe
+        a.melt_tmp[v] = meltn;          // neighbours still read the old melt_n
+        a.m0[v] = melt0;
+    }
+}
+
+// b <- max(b + dt (Melt(q_new, h, G, b, melt_new)/rho_i - Closure(b, N)), b_min); N_n <- N
+// (solvers.py:162,192,196,228)
+__global__ __launch_bounds__(kBlock) void k_update_b(const UpdArgs a) {
+    const DevParams& p = a.p;
+    for (int64_t v = blockIdx.x * (int64_t)kBlock + threadIdx.x; v < a.nv; v += (int64_t)gridDim.x * kBlock) {
+        const CellGeom g = cell_geom(a.m, a.lastcell[v]);
+        const double b0 = a.b[g.v0], b1 = a.b[g.v1], b2 = a.b[g.v2];
+        const double gbx = b0 * g.g0x + b1 * g.g1x + b2 * g.g2x, gby = b0 * g.g0y + b1 * g.g1y + b2 * g.g2y;
+        const double m0_ = a.melt_tmp[g.v0], m1_ = a.melt_tmp[g.v1], m2_ = a.melt_tmp[g.v2];
+        const double gmx = m0_ * g.g0x + m1_ * g.g1x + m2_ * g.g2x, gmy = m0_ * g.g0y + m1_ * g.g1y + m2_ * g.g2y;
+        const double bv = a.b[v], mv = a.melt_tmp[v], Nv = a.N[v];
+        const double gb2 = gbx * gbx + gby * gby;
+        const double melt = a.m0[v] + (mv * gb2 + bv * (gmx * gbx + gmy * gby)) / (1.0 + gb2);
+        const double closure = p.A * bv * Nv * glen_pow(Nv, p);
+        double bn = bv + a.dt * (melt / p.rho_i - closure);
+        bn = (bn < p.b_min) ? p.b_min : bn;
+        a.b_tmp[v] = bn;
+        a.N_n[v] = Nv;
+    }
+}
+
+void launch_update_explicit(Ctx* c, double dt) {
+    UpdArgs a;
+    a.m.xy = c->d_xy; a.m.cells = c->d_cells;
+    a.lastcell = c->d_lastcell;
+    a.N = c->f[SHK_N]; a.z_b = c->f[SHK_Z_B]; a.z_s = c->f[SHK_Z_S]; a.G = c->f[SHK_G];
+    a.b = c->f[SHK_B]; a.qx = c->f[SHK_QX]; a.qy = c->f[SHK_QY]; a.melt_n = c->f[SHK_MELT_N];
+    a.N_n = c->f[SHK_N_N];
+    a.melt_tmp = c->d_melt_tmp; a.b_tmp = c->d_b_tmp; a.m0 = c->d_m0;
+    a.dt = dt; a.nv = c->nv; a.p = c->dp;
+    int g = (int)std::min<int64_t>((c->nv + kBlock - 1) / kBlock, 4096);
+    {
+        PhaseTimer t(c, SHK_PH_UPDATE);
+        hipLaunchKernelGGL(k_update_a, dim3(g), dim3(kBlock), 0, c->stream, a);
+    }
+    {
+        PhaseTimer t(c, SHK_PH_UPDATE);
+        hipLaunchKernelGGL(k_update_b, dim3(g), dim3(kBlock), 0, c->stream, a);
+    }
+    std::swap(c->f[SHK_MELT_N], c->d_melt_tmp);
+    std::swap(c->f[SHK_B], c->d_b_tmp);
+}
+
+// ------------------------------------------------------------------ q layout helpers
+__global__ void k_split_q(int64_t n, const double* __restrict__ q, double* __restrict__ qx, double* __restrict__ qy) {
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        qx[i] = q[2 * i]; qy[i] = q[2 * i + 1];
+    }
+}
+__global__ void k_join_q(int64_t n, const double* __restrict__ qx, const double* __restrict__ qy, double* __restrict__ q) {
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        q[2 * i] = qx[i]; q[2 * i + 1] = qy[i];
+    }
+}
+void launch_split_q(Ctx* c, const double* q) {
+    hipLaunchKernelGGL(k_split_q, dim3(c->grid), dim3(kBlock), 0, c->stream, c->nv, q, c->f[SHK_QX], c->f[SHK_QY]);
+}
+void launch_join_q(Ctx* c, double* q) {
+    hipLaunchKernelGGL(k_join_q, dim3(c->grid), dim3(kBlock), 0, c->stream, c->nv, c->f[SHK_QX], c->f[SHK_QY], q);
+}
+
+// ------------------------------------------------------------------ profiling
+PhaseTimer::PhaseTimer(Ctx* c_, int phase) : c(c_) {
+    if (!c->profiling) return;
+    if (c->ev_used == c->ev_pool.size()) {
+        Ctx::Ev e;
+        hipEventCreate(&e.a);
+        hipEventCreate(&e.b);
+        c->ev_pool.push_back(e);
+    }
+    idx = (int)c->ev_used++;
+    c->ev_pool[idx].phase = phase;
+    hipEventRecord(c->ev_pool[idx].a, c->stream);
+}
+PhaseTimer::~PhaseTimer() {
+    if (idx >= 0) hipEventRecord(c->ev_pool[idx].b, c->stream);
+}
+
+}  // namespace shk

@@ -1,0 +1,42 @@
+"""Shared builders for tests: the same seeded synthetic case for the oracle and the HIP path."""
+import numpy as np
+
+import shakti_oracle as O
+from shakti_fenics_amd.mesh import rectangle_mesh
+from shakti_fenics_amd.synthetic import N_BDRY, outflow_predicate, synthetic_fields
+
+
+def make_case(nx=31, ny=23, Lx=10e3, Ly=8e3, order="morton", storage_on=True, raw_b=False, moulins=0,
+              perturb=False, seed=5):
+    """Mesh + oracle Fields + Dirichlet dofs.  perturb=True puts every field in a generic state
+    (N away from N_n, q and melt_n non-zero) so that every term of the form is exercised."""
+    dom = rectangle_mesh(nx, ny, Lx, Ly, order=order)
+    sf = synthetic_fields(dom, storage_on=storage_on, moulins=moulins)
+    nv = dom.num_vertices
+    b = sf["b_init"] if raw_b else np.abs(sf["b_init"])
+    f = O.Fields(N=sf["N_init"].copy(), N_n=sf["N_init"].copy(), b=b.copy(), q=sf["q_init"].copy(),
+                 melt_n=np.zeros(nv), z_b=sf["z_b"], z_s=sf["z_s"], G=sf["G"], storage=sf["lake_bdry"],
+                 inputs=sf["inputs"])
+    if perturb:
+        rng = np.random.default_rng(seed)
+        f.N = f.N * (1.0 + 0.2 * rng.normal(size=nv))
+        f.q = 2e-3 * rng.normal(size=(nv, 2))
+        f.melt_n = 1e-7 * rng.uniform(size=nv)
+        f.storage = rng.uniform(size=nv) * (rng.uniform(size=nv) < 0.5)
+        f.inputs = 1e-9 * rng.uniform(size=nv)
+    bc = O.boundary_dofs(dom.xy, dom.cells, outflow_predicate(dom))
+    return dom, f, bc, N_BDRY
+
+
+def upload(ctx, f, bc=None, bc_value=0.0):
+    for name in ("N", "N_n", "b", "q", "melt_n", "z_b", "z_s", "G", "storage", "inputs"):
+        ctx.set_field(name, getattr(f, name))
+    if bc is not None:
+        ctx.set_dirichlet(bc, bc_value)
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, dtype=np.float64).ravel()
+    b = np.asarray(b, dtype=np.float64).ravel()
+    nb = np.linalg.norm(b)
+    return np.linalg.norm(a - b) / (nb if nb > 0 else 1.0)

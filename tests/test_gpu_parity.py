@@ -1,0 +1,133 @@
+"""HIP path vs the CPU oracle through the C ABI (needs an MI355X: pytest -m gpu).
+
+Tolerances: the two sides run the same fp64 algorithm with different summation orders, so
+element-level quantities agree to ~1e-12 relative; after a Newton solve (exact LU in the oracle,
+Jacobi-BiCGStab driven to 1e-10 on the GPU) fields agree to <= 1e-8, far inside the 1e-6 rel-L2
+bar BASELINE.json states for the head / effective-pressure field.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import shakti_oracle as O
+from cases import make_case, rel_l2, upload
+
+pytestmark = pytest.mark.gpu
+
+DT = 3600.0
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from shakti_fenics_amd import _lib
+    _lib.load()  # fails loudly if the extension is not built
+    return _lib
+
+
+@pytest.mark.parametrize("order", ["morton", "random"])
+@pytest.mark.parametrize("with_bc", [False, True])
+def test_assemble_matches_oracle(hip, order, with_bc):
+    dom, f, bc, g = make_case(order=order, perturb=True, raw_b=True)
+    if with_bc:
+        f.N[bc[::2]] = g  # some Dirichlet dofs already satisfied, others not -> lifting is exercised
+    ctx = hip.ShaktiHip(dom.xy, dom.cells)
+    upload(ctx, f, bc if with_bc else None, g)
+    ctx.assemble(DT)
+    F = ctx.residual()
+    rp, ci, va = ctx.csr()
+    prm = O.Params()
+    Fo, Jo = O.assemble(dom.xy, dom.cells, f, DT, prm, bc if with_bc else None, g)
+    rpo, cio = O.csr_pattern(dom.num_vertices, dom.cells)
+    assert np.array_equal(rp, rpo) and np.array_equal(ci, cio)
+    J = sp.csr_matrix((va, ci, rp), shape=Jo.shape)
+    assert rel_l2(F, Fo) < 1e-11
+    assert abs(J - Jo).max() / abs(Jo).max() < 1e-12
+    ctx.close()
+
+
+def test_spmv_matches_scipy(hip):
+    dom, f, bc, g = make_case(perturb=True)
+    ctx = hip.ShaktiHip(dom.xy, dom.cells)
+    upload(ctx, f, bc, g)
+    ctx.assemble(DT)
+    rp, ci, va = ctx.csr()
+    J = sp.csr_matrix((va, ci, rp), shape=(dom.num_vertices,) * 2)
+    x = np.random.default_rng(0).normal(size=dom.num_vertices)
+    assert rel_l2(ctx.spmv(x), J @ x) < 1e-13
+    ctx.close()
+
+
+def test_linear_solve(hip):
+    dom, f, bc, g = make_case(perturb=True)
+    ctx = hip.ShaktiHip(dom.xy, dom.cells)
+    upload(ctx, f, bc, g)
+    ctx.assemble(DT)
+    its, conv, rr = ctx.linear_solve()
+    assert conv and rr <= 1e-10 and its > 0
+    rp, ci, va = ctx.csr()
+    J = sp.csr_matrix((va, ci, rp), shape=(dom.num_vertices,) * 2)
+    F = ctx.residual()
+    dx = ctx.get_field("dx")
+    assert np.linalg.norm(J @ dx - F) / np.linalg.norm(F) < 1e-9
+    # the CPU twin of the same recurrence needs a similar number of iterations
+    _, its_cpu, _ = O.jacobi_bicgstab(J, F, 1e-10, 1e-50, 20000)
+    assert abs(its - its_cpu) <= max(5, 0.25 * its_cpu)
+    ctx.close()
+
+
+@pytest.mark.parametrize("raw_b", [False, True])
+def test_newton_and_update_match_oracle(hip, raw_b):
+    dom, f, bc, g = make_case(raw_b=raw_b)
+    ctx = hip.ShaktiHip(dom.xy, dom.cells)
+    upload(ctx, f, bc, g)
+    prm = O.Params()
+    fo = f.copy()
+    info = ctx.newton_solve(0.1 * DT)
+    n_o, conv_o, log = O.newton_solve(dom.xy, dom.cells, fo, 0.1 * DT, prm, bc, g)
+    assert info.converged and conv_o
+    assert info.newton_its == n_o
+    assert rel_l2(ctx.get_field("N"), fo.N) < 1e-8
+    # explicit updates from IDENTICAL inputs (upload the oracle's N) agree to round-off
+    ctx.set_field("N", fo.N)
+    ctx.update_explicit(0.1 * DT)
+    O.update_explicit(dom.xy, dom.cells, fo, 0.1 * DT, prm)
+    assert rel_l2(ctx.get_field("q"), fo.q) < 1e-12
+    assert rel_l2(ctx.get_field("melt_n"), fo.melt_n) < 1e-12
+    assert rel_l2(ctx.get_field("b"), fo.b) < 1e-12
+    assert np.array_equal(ctx.get_field("N_n"), fo.N_n)
+    ctx.close()
+
+
+def test_ten_steps_match_oracle(hip):
+    dom, f, bc, g = make_case(nx=41, ny=31)
+    ctx = hip.ShaktiHip(dom.xy, dom.cells)
+    upload(ctx, f, bc, g)
+    ts = np.arange(11) * DT
+    fo, log = O.run(dom.xy, dom.cells, f.copy(), ts, O.Params(), bc, g, nsteps=10)
+    its = []
+    for i in range(10):
+        dt = 0.1 * DT if i == 0 else DT
+        info = ctx.step(dt)
+        assert info.converged
+        its.append(info.newton_its)
+    assert its == [l["niter"] for l in log]
+    assert rel_l2(ctx.get_field("N"), fo.N) < 1e-7
+    assert rel_l2(ctx.get_field("b"), fo.b) < 1e-7
+    assert rel_l2(ctx.get_field("q"), fo.q) < 1e-6
+    ctx.close()
+
+
+def test_errors_are_loud(hip):
+    dom, f, bc, g = make_case()
+    ctx = hip.ShaktiHip(dom.xy, dom.cells)
+    with pytest.raises(hip.ShaktiHipError):
+        ctx.residual()  # nothing assembled yet
+    with pytest.raises(hip.ShaktiHipError):
+        ctx.assemble(-1.0)
+    with pytest.raises(hip.ShaktiHipError):
+        ctx.set_dirichlet([dom.num_vertices + 5], 0.0)
+    bad = dom.cells.copy()
+    bad[0, 0] = dom.num_vertices
+    with pytest.raises(hip.ShaktiHipError):
+        hip.ShaktiHip(dom.xy, bad)
+    ctx.close()
