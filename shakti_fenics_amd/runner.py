@@ -1,0 +1,93 @@
+"""Benchmark / smoke driver around one device context: builds a synthetic configuration
+(SURVEY.md section 8d), keeps every field resident in HBM and advances the solve loop of
+`/root/reference/source/solvers.py:168-229` one time step per call."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+from .bc import locate_boundary_dofs
+from .mesh import rectangle_mesh
+from .synthetic import CONFIGS, N_BDRY, outflow_predicate, synthetic_fields
+
+
+class SingleRunner:
+    def __init__(self, config="c4_10m", order="morton", dt=3600.0, storage=False, moulins=0, device=0,
+                 krylov_rtol=1e-10, shape=None):
+        nx, ny, Lx, Ly = CONFIGS[config] if shape is None else shape
+        self.dom = rectangle_mesh(nx, ny, Lx, Ly, order=order)
+        self.dt = dt
+        sf = synthetic_fields(self.dom, storage_on=storage, moulins=moulins)
+        self.ctx = _lib.ShaktiHip(self.dom.xy, self.dom.cells, device=device)
+        self.ctx.set_params(krylov_rtol=krylov_rtol)
+        c = self.ctx
+        c.set_field("z_b", sf["z_b"]); c.set_field("z_s", sf["z_s"]); c.set_field("G", sf["G"])
+        c.set_field("inputs", sf["inputs"]); c.set_field("storage", sf["lake_bdry"])
+        # |b_init|: the reference's 0.001 + N(0, 0.005) draw (setup_cooke2.py:66) enters its flux law only
+        # through |b|^3 (constitutive.py:14); see DESIGN.md "synthetic initial gap height"
+        c.set_field("b", np.abs(sf["b_init"]))
+        c.set_field("N_n", sf["N_init"]); c.set_field("N", sf["N_init"])  # initial guess, solvers.py:48
+        c.set_field("q", sf["q_init"]); c.set_field("melt_n", np.zeros(self.dom.num_vertices))
+        self.bc = locate_boundary_dofs(self.dom, outflow_predicate(self.dom))
+        c.set_dirichlet(self.bc, N_BDRY)
+        st = c.plan_stats()
+        self.nv_global, self.ne_global, self.nnz_global = st["nv"], st["ne"], st["nnz"]
+        self.stats = st
+        self._desc = (f"{Lx/1e3:.0f} km x {Ly/1e3:.0f} km rectangle, {nx}x{ny} jittered P1 mesh ({order} order), "
+                      f"dt {dt:g} s (first step 0.1 dt), storage {'on' if storage else 'off'}, {moulins} moulins, "
+                      f"Dirichlet N = {N_BDRY:g} Pa on x = 0")
+        self.next_step = 0
+
+    def describe(self):
+        return self._desc
+
+    def step(self, i=None):
+        i = self.next_step if i is None else i
+        dt = 0.1 * self.dt if i == 0 else self.dt  # solvers.py:81,174-176
+        info = self.ctx.step(dt)
+        if not info.converged:
+            raise RuntimeError(f"Newton did not converge at step {i}: residual {info.residual:g} "
+                               f"after {info.newton_its} iterations")  # error_on_nonconvergence=True
+        self.next_step = i + 1
+        return info
+
+    def sync(self):
+        self.ctx.sync()
+
+    def roofline(self, peak_gbs: float) -> dict:
+        """Per-launch hipEvent timing of one more step on the library's stream; the dominant kernel
+        is the CSR SpMV (two launches per BiCGStab iteration)."""
+        c = self.ctx
+        c.profile_enable(True)
+        c.profile_read(reset=True)
+        info = self.step()
+        prof = c.profile_read(reset=True)
+        c.profile_enable(False)
+        nv, nnz = self.nv_global, self.nnz_global
+        # algorithmic bytes of one CSR SpMV launch: values 8 nnz + colidx 4 nnz + rowptr 4 (nv+1)
+        # + x 8 nv + y 8 nv   (104 nv at nnz = 7 nv)
+        spmv_bytes = 12 * nnz + 4 * (nv + 1) + 16 * nv
+        asm_bytes = 12 * self.ne_global + 16 * nv + 88 * nv + 8 * nv + 8 * nnz  # 192 nv
+        ms = prof["spmv"]["ms"] / max(prof["spmv"]["launches"], 1)
+        ach = spmv_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        asm_ms = prof["assemble"]["ms"] / max(prof["assemble"]["launches"], 1)
+        return {
+            "bound": "hbm", "kernel": "k_spmv (CSR-stream SpMV + fused BiCGStab dots)",
+            "achieved": ach, "peak": peak_gbs, "unit": "GB/s", "frac": ach / peak_gbs, "traffic": None,
+            "bytes_per_launch": spmv_bytes, "avg_launch_ms": ms, "launches": prof["spmv"]["launches"],
+            "assemble": {"avg_launch_ms": asm_ms, "bytes_per_launch": asm_bytes,
+                         "achieved": asm_bytes / (asm_ms * 1e-3) / 1e9 if asm_ms > 0 else 0.0,
+                         "launches": prof["assemble"]["launches"]},
+            "phase_ms": {k: v["ms"] for k, v in prof.items()},
+            "profiled_step": {"newton_its": info.newton_its, "krylov_its": info.krylov_its},
+        }
+
+    def close(self):
+        self.ctx.close()
+
+
+def make_runner(args, rank: int, world: int, local_rank: int):
+    if world == 1:
+        return SingleRunner(args.config, args.order, args.dt, bool(args.storage), args.moulins, local_rank,
+                            args.krylov_rtol)
+    raise NotImplementedError("domain-decomposed runner is built in shakti_fenics_amd/partition.py")
