@@ -12,7 +12,8 @@
  *  - shk_ctx is opaque; one context per GPU (per subdomain); a context is not thread-safe;
  *  - the caller owns all host arrays (borrowed for the duration of the call, C-contiguous,
  *    float64 / int32); the library owns all device memory;
- *  - vertex fields are length nv; SHK_Q is length 2*nv interleaved [x0,y0,x1,y1,...] (DOLFINx's
+ *  - vertex arrays are in the CALLER's numbering (the library renumbers internally for locality) and
+ *    have length nv (= owned + ghost for a subdomain); SHK_Q is length 2*nv interleaved [x0,y0,x1,y1,...] (DOLFINx's
  *    blocked P1-vector layout, solvers.py:130,139-140);
  *  - all arithmetic is float64 (PETSc.ScalarType, solvers.py:24).
  */
@@ -84,6 +85,12 @@ int shk_version(void);
  * Replaces mesh + function-space + matrix preallocation: setup_cooke2.py:19, model_setup.py:29-30,
  * solvers.py:51-52.  xy is (nv,2), cells is (ne,3); cell order defines "last cell wins". */
 int shk_create(int device_id, int64_t nv, int64_t ne, const double* xy, const int32_t* cells, shk_ctx** out);
+/* One subdomain of a domain-decomposed mesh (the DOLFINx distributed mesh: owned + ghost dofs,
+ * model_setup.py:108-116).  Local vertices [0, n_own) are owned, [n_own, n_own+n_ghost) are ghosts;
+ * `cells` lists, in ascending GLOBAL cell order, every cell that touches an owned vertex, in local ids.
+ * All vertex arrays of this context have length n_own + n_ghost.  shk_create == n_ghost 0. */
+int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, const double* xy,
+                     const int32_t* cells, shk_ctx** out);
 int shk_destroy(shk_ctx* ctx);
 
 int shk_default_params(shk_params* p);
@@ -130,8 +137,9 @@ int shk_profile_read(shk_ctx* ctx, shk_profile* out, int32_t reset);
 /* Launch kernel `phase` (SHK_PH_ASSEMBLE or SHK_PH_SPMV) `reps` times between two events. */
 int shk_time_kernel(shk_ctx* ctx, int32_t phase, int32_t reps, double dt, double* avg_ms);
 
-/* Plan statistics for DESIGN.md / bench: n[0]=nv n[1]=ne n[2]=nnz n[3]=assembly blocks
- * n[4]=cells computed incl. redundant n[5]=spmv row blocks n[6]=device bytes n[7]=max row length */
+/* Plan statistics for DESIGN.md / bench: n[0]=owned rows n[1]=ne n[2]=nnz n[3]=assembly blocks
+ * n[4]=cells computed per assembly incl. cells shared between blocks n[5]=SELL slots (padded nnz)
+ * n[6]=device bytes n[7]=max row length */
 int shk_plan_stats(shk_ctx* ctx, int64_t n[8]);
 
 #ifdef __cplusplus

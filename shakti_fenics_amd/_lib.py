@@ -42,7 +42,7 @@ FIELDS = dict(N=0, N_n=1, b=2, q=3, z_b=4, z_s=5, G=6, melt_n=7, storage=8, inpu
 
 # every symbol include/shakti_hip.h declares (tests/test_abi.py checks the .so exports all of them)
 EXPORTS = (
-    "shk_last_error", "shk_version", "shk_create", "shk_destroy", "shk_default_params", "shk_set_params",
+    "shk_last_error", "shk_version", "shk_create", "shk_create_local", "shk_destroy", "shk_default_params", "shk_set_params",
     "shk_get_params", "shk_set_quadrature", "shk_set_field", "shk_get_field", "shk_set_dirichlet",
     "shk_assemble", "shk_get_residual", "shk_csr_nnz", "shk_get_csr", "shk_linear_solve", "shk_spmv",
     "shk_newton_solve", "shk_update_explicit", "shk_step", "shk_sync", "shk_profile_enable",
@@ -68,6 +68,7 @@ def load():
     sig = {
         "shk_version": ([], C.c_int),
         "shk_create": ([C.c_int, i64, i64, vp, vp, P(vp)], C.c_int),
+        "shk_create_local": ([C.c_int, i64, i64, i64, vp, vp, P(vp)], C.c_int),
         "shk_destroy": ([vp], C.c_int),
         "shk_default_params": ([P(shk_params)], C.c_int),
         "shk_set_params": ([vp, P(shk_params)], C.c_int),
@@ -113,15 +114,18 @@ def _f64(a, shape=None) -> np.ndarray:
 class ShaktiHip:
     """One device context: mesh + fields + solver state resident in HBM."""
 
-    def __init__(self, xy, cells, device: int = 0):
+    def __init__(self, xy, cells, device: int = 0, n_own: int | None = None):
+        """n_own < len(xy) makes this a subdomain context: vertices [n_own, nv) are ghosts."""
         self.lib = load()
         xy = _f64(xy)
         cells = np.ascontiguousarray(cells, dtype=np.int32)
         if xy.ndim != 2 or xy.shape[1] != 2 or cells.ndim != 2 or cells.shape[1] != 3:
             raise ValueError("xy must be (nv,2) float64 and cells (ne,3) int32")
         self.nv, self.ne = xy.shape[0], cells.shape[0]
+        self.n_own = self.nv if n_own is None else int(n_own)
         h = C.c_void_p()
-        self._check(self.lib.shk_create(device, self.nv, self.ne, _ptr(xy), _ptr(cells), C.byref(h)))
+        self._check(self.lib.shk_create_local(device, self.n_own, self.nv - self.n_own, self.ne, _ptr(xy),
+                                              _ptr(cells), C.byref(h)))
         self._h = h
 
     def _check(self, rc):
@@ -239,5 +243,5 @@ class ShaktiHip:
     def plan_stats(self) -> dict:
         n = (C.c_int64 * 8)()
         self._check(self.lib.shk_plan_stats(self._h, n))
-        keys = ("nv", "ne", "nnz", "asm_blocks", "asm_cells_computed", "spmv_blocks", "device_bytes", "max_row_len")
+        keys = ("nv", "ne", "nnz", "asm_blocks", "asm_cells_computed", "sell_slots", "device_bytes", "max_row_len")
         return dict(zip(keys, [int(v) for v in n]))

@@ -99,18 +99,20 @@ int shk_default_params(shk_params* p) {
     return 0;
 }
 
-int shk_create(int device_id, int64_t nv, int64_t ne, const double* xy, const int32_t* cells, shk_ctx** out) {
+int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, const double* xy,
+                     const int32_t* cells, shk_ctx** out) {
     if (!out) return fail("null output pointer");
     *out = nullptr;
     if (!xy || !cells) return fail("null mesh arrays");
-    if (nv < 3 || ne < 1) return fail("mesh needs at least one triangle");
+    if (n_own < 1 || n_ghost < 0 || n_own + n_ghost < 3 || ne < 1) return fail("mesh needs at least one triangle");
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (device_id < 0 || device_id >= ndev) return fail("device_id out of range: no such GPU");
     HIPCHK(hipSetDevice(device_id));
     Ctx* c = new Ctx();
     c->device = device_id;
-    c->nv = nv;
+    c->n_own = n_own;
+    c->n_loc = n_own + n_ghost;
     c->ne = ne;
     shk_default_params(&c->params);
     derive_params(c);
@@ -119,19 +121,22 @@ int shk_create(int device_id, int64_t nv, int64_t ne, const double* xy, const in
         if (set_quadrature(c, SHK_NQ_DEFAULT, q)) { delete c; return -1; }
     }
     PlanOptions opt;
-    if (const char* s = getenv("SHK_ASM_ROWS")) opt.rows_max = std::max(16, atoi(s));
+    if (const char* s = getenv("SHK_ASM_SLICES")) opt.slices_max = std::max(1, atoi(s));
     if (const char* s = getenv("SHK_ASM_CELLS")) opt.cells_max = std::max(64, atoi(s));
-    opt.spmv_nnz = kSpmvNnz;  // the LDS product buffer of k_spmv
-    std::string err = build_plan(nv, ne, cells, opt, c->plan);
+    if (const char* s = getenv("SHK_SORT_WINDOW")) opt.sort_window = std::max(64, atoi(s));
+    if (const char* s = getenv("SHK_REORDER")) opt.reorder = atoi(s) != 0;
+    std::string err = build_plan(c->n_own, c->n_loc, ne, xy, cells, opt, c->plan);
     if (!err.empty()) { delete c; return fail("plan: " + err); }
-    c->nnz = c->plan.nnz;
-    c->nblk = (int)c->plan.blk_row0.size() - 1;
-    c->nsb = (int)c->plan.sp_row0.size() - 1;
-    c->grid = (int)std::min<int64_t>(kMaxParts, std::max<int64_t>(1, (nv + kBlock - 1) / kBlock));
+    const HostPlan& P = c->plan;
+    c->nnz = P.A.nnz;
+    c->slots = P.A.slots;
+    c->nblk = (int)P.blk_slice0.size() - 1;
+    c->cells_staged = (int64_t)P.blk_cells.size();
+    c->grid = (int)std::min<int64_t>(kMaxParts, std::max<int64_t>(1, (c->n_own + kBlock - 1) / kBlock));
     {
-        const size_t E = c->plan.cells_max, R = c->plan.rows_max;
-        size_t lds = 12 * E * sizeof(double) + 3 * E * sizeof(int) + 2 * (R + 1) * sizeof(int) +
-                     (size_t)c->plan.max_inc_per_block * sizeof(uint16_t);
+        const size_t E = P.cells_max, S = P.slices_max;
+        size_t lds = 12 * E * sizeof(double) + 3 * E * sizeof(int) + (S + 1) * sizeof(int) +
+                     (S * kSlice + 1) * sizeof(int) + (size_t)P.max_inc_per_block * sizeof(uint16_t);
         c->asm_lds = (lds + 15) & ~size_t(15);
         if (c->asm_lds > 160 * 1024) { delete c; return fail("assembly LDS budget exceeds 160 KiB"); }
     }
@@ -141,39 +146,44 @@ int shk_create(int device_id, int64_t nv, int64_t ne, const double* xy, const in
         return fail(m);
     };
     hipError_t e;
+    const size_t nl = (size_t)c->n_loc;
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "stream");
-    // mesh
-    if ((e = dev_alloc(c, &c->d_xy, (size_t)nv)) != hipSuccess) return bail(e, "alloc xy");
-    if ((e = hipMemcpy(c->d_xy, xy, (size_t)nv * sizeof(double2), hipMemcpyHostToDevice)) != hipSuccess)
+    if ((e = hipEventCreateWithFlags(&c->poll_ev[0], hipEventDisableTiming)) != hipSuccess) return bail(e, "event");
+    if ((e = hipEventCreateWithFlags(&c->poll_ev[1], hipEventDisableTiming)) != hipSuccess) return bail(e, "event");
+    // mesh (internal numbering)
+    if ((e = dev_alloc(c, &c->d_xy, nl)) != hipSuccess) return bail(e, "alloc xy");
+    if ((e = hipMemcpy(c->d_xy, P.xy.data(), nl * sizeof(double2), hipMemcpyHostToDevice)) != hipSuccess)
         return bail(e, "copy xy");
-    if ((e = dev_alloc(c, &c->d_cells, (size_t)ne * 3)) != hipSuccess) return bail(e, "alloc cells");
-    if ((e = hipMemcpy(c->d_cells, cells, (size_t)ne * 3 * sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess)
-        return bail(e, "copy cells");
-    // plan
-    const HostPlan& P = c->plan;
 #define UP(dst, src) if ((e = upload(c, &c->dst, P.src)) != hipSuccess) return bail(e, "upload " #src)
-    UP(d_rowptr, rowptr); UP(d_colidx, colidx); UP(d_diagpos, diagpos); UP(d_lastcell, lastcell);
-    UP(d_blk_row0, blk_row0); UP(d_blk_cellptr, blk_cellptr); UP(d_blk_cells, blk_cells); UP(d_incptr, incptr);
-    UP(d_inccode, inccode); UP(d_sp_row0, sp_row0);
+    UP(d_cells, cells); UP(d_perm, perm); UP(d_sell_ptr, A.ptr); UP(d_sell_col, A.col); UP(d_rowlen, A.rowlen);
+    UP(d_lastcell, lastcell); UP(d_blk_slice0, blk_slice0); UP(d_blk_cellptr, blk_cellptr);
+    UP(d_blk_cells, blk_cells); UP(d_incptr, incptr); UP(d_inccode, inccode);
 #undef UP
-    // fields
+    // the host copies of the big plan arrays are no longer needed (the SELL pattern stays for get_csr)
+    c->plan.xy = std::vector<double>();
+    c->plan.cells = std::vector<int32_t>();
+    c->plan.blk_cells = std::vector<int32_t>();
+    c->plan.inccode = std::vector<uint16_t>();
+    c->plan.incptr = std::vector<int32_t>();
+    c->plan.lastcell = std::vector<int32_t>();
+    if ((e = dev_alloc(c, &c->d_io, 2 * nl)) != hipSuccess) return bail(e, "alloc io");
     for (int fidx = 0; fidx < SHK_FIELD_COUNT; ++fidx) {
         if (fidx == SHK_Q) continue;
-        if ((e = dev_alloc(c, &c->f[fidx], (size_t)nv)) != hipSuccess) return bail(e, "alloc field");
-        if ((e = hipMemset(c->f[fidx], 0, (size_t)nv * sizeof(double))) != hipSuccess) return bail(e, "memset");
+        if ((e = dev_alloc(c, &c->f[fidx], nl)) != hipSuccess) return bail(e, "alloc field");
+        if ((e = hipMemset(c->f[fidx], 0, nl * sizeof(double))) != hipSuccess) return bail(e, "memset");
     }
     double** vecs[] = {&c->d_melt_tmp, &c->d_b_tmp, &c->d_m0, &c->d_F, &c->d_dinv, &c->d_r, &c->d_rhat,
                        &c->d_p, &c->d_v, &c->d_s, &c->d_t, &c->d_y};
     for (double** v : vecs) {
-        if ((e = dev_alloc(c, v, (size_t)nv)) != hipSuccess) return bail(e, "alloc vector");
-        if ((e = hipMemset(*v, 0, (size_t)nv * sizeof(double))) != hipSuccess) return bail(e, "memset");
+        if ((e = dev_alloc(c, v, nl)) != hipSuccess) return bail(e, "alloc vector");
+        if ((e = hipMemset(*v, 0, nl * sizeof(double))) != hipSuccess) return bail(e, "memset");
     }
-    if ((e = dev_alloc(c, &c->d_vals, (size_t)c->nnz)) != hipSuccess) return bail(e, "alloc vals");
-    if ((e = dev_alloc(c, &c->d_vals_s, (size_t)c->nnz)) != hipSuccess) return bail(e, "alloc vals_s");
-    if ((e = dev_alloc(c, &c->d_bcflag, (size_t)nv)) != hipSuccess) return bail(e, "alloc bcflag");
-    if ((e = hipMemset(c->d_bcflag, 0, (size_t)nv)) != hipSuccess) return bail(e, "memset");
-    if ((e = dev_alloc(c, &c->d_part, (size_t)6 * kMaxParts)) != hipSuccess) return bail(e, "alloc partials");
-    if ((e = hipMemset(c->d_part, 0, 6 * kMaxParts * sizeof(double))) != hipSuccess) return bail(e, "memset");
+    if ((e = dev_alloc(c, &c->d_vals, (size_t)c->slots)) != hipSuccess) return bail(e, "alloc vals");
+    if ((e = dev_alloc(c, &c->d_vals_s, (size_t)c->slots)) != hipSuccess) return bail(e, "alloc vals_s");
+    if ((e = dev_alloc(c, &c->d_bcflag, nl)) != hipSuccess) return bail(e, "alloc bcflag");
+    if ((e = hipMemset(c->d_bcflag, 0, nl)) != hipSuccess) return bail(e, "memset");
+    if ((e = dev_alloc(c, &c->d_part, (size_t)P_COUNT * kMaxParts)) != hipSuccess) return bail(e, "alloc partials");
+    if ((e = hipMemset(c->d_part, 0, P_COUNT * kMaxParts * sizeof(double))) != hipSuccess) return bail(e, "memset");
     if ((e = dev_alloc(c, &c->d_state, 1)) != hipSuccess) return bail(e, "alloc state");
     if ((e = hipMemset(c->d_state, 0, sizeof(KrylovState))) != hipSuccess) return bail(e, "memset");
     if ((e = hipHostMalloc((void**)&c->h_state, 2 * sizeof(KrylovState))) != hipSuccess) return bail(e, "pinned");
@@ -183,16 +193,21 @@ int shk_create(int device_id, int64_t nv, int64_t ne, const double* xy, const in
     return 0;
 }
 
+int shk_create(int device_id, int64_t nv, int64_t ne, const double* xy, const int32_t* cells, shk_ctx** out) {
+    return shk_create_local(device_id, nv, 0, ne, xy, cells, out);
+}
+
 int shk_destroy(shk_ctx* ctx) {
     if (!ctx) return 0;
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
-    hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
-    for (auto& ev : c->ev_pool) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
-    for (void* p : c->allocs) hipFree(p);
-    if (c->h_state) hipHostFree(c->h_state);
-    if (c->h_part) hipHostFree(c->h_part);
-    if (c->stream) hipStreamDestroy(c->stream);
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& ev : c->ev_pool) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    for (hipEvent_t ev : c->poll_ev) if (ev) (void)hipEventDestroy(ev);
+    for (void* p : c->allocs) (void)hipFree(p);
+    if (c->h_state) (void)hipHostFree(c->h_state);
+    if (c->h_part) (void)hipHostFree(c->h_part);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
 }
@@ -229,18 +244,20 @@ int shk_set_field(shk_ctx* ctx, int32_t field, const double* host) {
     if (field < 0 || field >= SHK_FIELD_COUNT || field == SHK_DX) return fail("field id not settable");
     HIPCHK(hipSetDevice(c->device));
     c->assembled = false;
-    if (field == SHK_Q) {
-        // interleaved (nv,2) -> qx, qy; d_r/d_p are free scratch outside a linear solve
-        double* tmp = nullptr;
-        HIPCHK(hipMalloc((void**)&tmp, (size_t)c->nv * 2 * sizeof(double)));
-        hipError_t e = hipMemcpyAsync(tmp, host, (size_t)c->nv * 2 * sizeof(double), hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) { launch_split_q(c, tmp); e = hipStreamSynchronize(c->stream); }
-        hipFree(tmp);
-        HIPCHK(e);
-        return 0;
-    }
-    HIPCHK(hipMemcpyAsync(c->f[field], host, (size_t)c->nv * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const size_t n = (size_t)c->n_loc * (field == SHK_Q ? 2 : 1);
+    HIPCHK(hipMemcpyAsync(c->d_io, host, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (field == SHK_Q) launch_split_q(c, c->d_io);
+    else launch_permute_in(c, c->d_io, c->f[field]);
     HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int get_vector(Ctx* c, const double* dev, double* host) {
+    launch_permute_out(c, dev, c->d_io);
+    HIPCHK(hipMemcpyAsync(host, c->d_io, (size_t)c->n_loc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipGetLastError());
     return 0;
 }
 
@@ -251,18 +268,13 @@ int shk_get_field(shk_ctx* ctx, int32_t field, double* host) {
     if (field < 0 || field >= SHK_FIELD_COUNT) return fail("unknown field id");
     HIPCHK(hipSetDevice(c->device));
     if (field == SHK_Q) {
-        double* tmp = nullptr;
-        HIPCHK(hipMalloc((void**)&tmp, (size_t)c->nv * 2 * sizeof(double)));
-        launch_join_q(c, tmp);
-        hipError_t e = hipMemcpyAsync(host, tmp, (size_t)c->nv * 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        hipFree(tmp);
-        HIPCHK(e);
+        launch_join_q(c, c->d_io);
+        HIPCHK(hipMemcpyAsync(host, c->d_io, (size_t)c->n_loc * 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipGetLastError());
         return 0;
     }
-    HIPCHK(hipMemcpyAsync(host, c->f[field], (size_t)c->nv * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return 0;
+    return get_vector(c, c->f[field], host);
 }
 
 int shk_set_dirichlet(shk_ctx* ctx, int64_t n, const int32_t* dofs, double value) {
@@ -270,12 +282,12 @@ int shk_set_dirichlet(shk_ctx* ctx, int64_t n, const int32_t* dofs, double value
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (n < 0 || (n > 0 && !dofs)) return fail("bad dof list");
     HIPCHK(hipSetDevice(c->device));
-    std::vector<uint8_t> flag((size_t)c->nv, 0);
+    std::vector<uint8_t> flag((size_t)c->n_loc, 0);
     for (int64_t i = 0; i < n; ++i) {
-        if (dofs[i] < 0 || dofs[i] >= c->nv) return fail("Dirichlet dof outside [0, nv)");
-        flag[dofs[i]] = 1;
+        if (dofs[i] < 0 || dofs[i] >= c->n_loc) return fail("Dirichlet dof outside [0, nv)");
+        flag[c->plan.iperm[dofs[i]]] = 1;
     }
-    HIPCHK(hipMemcpy(c->d_bcflag, flag.data(), (size_t)c->nv, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_bcflag, flag.data(), (size_t)c->n_loc, hipMemcpyHostToDevice));
     c->has_bc = n > 0;
     c->bc_value = value;
     c->assembled = false;
@@ -300,9 +312,7 @@ int shk_get_residual(shk_ctx* ctx, double* host) {
     if (!host) return fail("null host array");
     if (!c->assembled) return fail("no assembled system: call shk_assemble first");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemcpyAsync(host, c->d_F, (size_t)c->nv * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return 0;
+    return get_vector(c, c->d_F, host);
 }
 
 int shk_csr_nnz(shk_ctx* ctx, int64_t* nnz) {
@@ -315,36 +325,53 @@ int shk_csr_nnz(shk_ctx* ctx, int64_t* nnz) {
 int shk_get_csr(shk_ctx* ctx, int32_t* rowptr, int32_t* colidx, double* values) {
     CHECK_CTX(ctx);
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
-    if (rowptr) std::memcpy(rowptr, c->plan.rowptr.data(), (size_t)(c->nv + 1) * sizeof(int32_t));
-    if (colidx) std::memcpy(colidx, c->plan.colidx.data(), (size_t)c->nnz * sizeof(int32_t));
+    std::vector<double> sv;
     if (values) {
         if (!c->assembled) return fail("no assembled system: call shk_assemble first");
         HIPCHK(hipSetDevice(c->device));
-        HIPCHK(hipMemcpyAsync(values, c->d_vals, (size_t)c->nnz * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        sv.resize((size_t)c->slots);
+        HIPCHK(hipMemcpyAsync(sv.data(), c->d_vals, sv.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
     }
+    std::vector<int32_t> rp, ci;
+    std::vector<double> va;
+    sell_to_csr(c->plan, values ? sv.data() : nullptr, rp, ci, values ? &va : nullptr);
+    if (rowptr) std::memcpy(rowptr, rp.data(), rp.size() * sizeof(int32_t));
+    if (colidx) std::memcpy(colidx, ci.data(), ci.size() * sizeof(int32_t));
+    if (values) std::memcpy(values, va.data(), va.size() * sizeof(double));
     return 0;
 }
 
-// Enqueue BiCGStab on the assembled system with rhs = F; returns after the device reports done.
+// Enqueue BiCGStab on the assembled system with rhs = F.  The host only polls a stop flag: chunk k+1 is
+// already queued when chunk k's flag is read, so the GPU never idles; kernels after the stop return
+// immediately.
 static int krylov_solve(Ctx* c, int* its, int* converged, double* relres) {
     launch_scale(c);
     krylov_init(c);
     const int chunk = std::max(1, c->params.krylov_check_every);
-    int it = 0;
-    KrylovState* hs = c->h_state;
-    for (;;) {
+    int it = 0, slot = 0;
+    KrylovState* fin = nullptr;
+    auto enqueue = [&](int sl) -> hipError_t {
         for (int k = 0; k < chunk; ++k) krylov_iteration(c, it + k);
         it += chunk;
-        HIPCHK(hipMemcpyAsync(hs, c->d_state, sizeof(KrylovState), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        if (hs->done) break;
-        if (it > c->params.krylov_max_it + chunk) return fail("Krylov driver ran past max_it without a stop flag");
+        hipError_t e = hipMemcpyAsync(&c->h_state[sl], c->d_state, sizeof(KrylovState), hipMemcpyDeviceToHost,
+                                      c->stream);
+        if (e != hipSuccess) return e;
+        return hipEventRecord(c->poll_ev[sl], c->stream);
+    };
+    HIPCHK(enqueue(slot));
+    for (;;) {
+        const int prev = slot;
+        slot ^= 1;
+        HIPCHK(enqueue(slot));
+        HIPCHK(hipEventSynchronize(c->poll_ev[prev]));
+        if (c->h_state[prev].done) { fin = &c->h_state[prev]; break; }
+        if (it > c->params.krylov_max_it + 4 * chunk) return fail("Krylov driver ran past max_it without a stop flag");
     }
     HIPCHK(hipGetLastError());
-    if (its) *its = hs->its;
-    if (converged) *converged = hs->converged;
-    if (relres) *relres = (hs->rhs2 > 0) ? std::sqrt(hs->rnorm2 / hs->rhs2) : 0.0;
+    if (its) *its = fin->its;
+    if (converged) *converged = fin->converged;
+    if (relres) *relres = (fin->rhs2 > 0) ? std::sqrt(fin->rnorm2 / fin->rhs2) : 0.0;
     return 0;
 }
 
@@ -356,8 +383,7 @@ int shk_linear_solve(shk_ctx* ctx, int32_t* its, int32_t* converged, double* rel
     int k = 0, cv = 0;
     double rr = 0;
     if (krylov_solve(c, &k, &cv, &rr)) return -1;
-    // dx = D^-1 y without touching N
-    launch_newton_update(c, false);
+    launch_newton_update(c, false);  // dx = D^-1 y without touching N
     HIPCHK(hipStreamSynchronize(c->stream));
     if (its) *its = k;
     if (converged) *converged = cv;
@@ -371,12 +397,11 @@ int shk_spmv(shk_ctx* ctx, const double* x_host, double* y_host) {
     if (!x_host || !y_host) return fail("null host array");
     if (!c->assembled) return fail("no assembled system: call shk_assemble first");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemcpyAsync(c->d_p, x_host, (size_t)c->nv * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_io, x_host, (size_t)c->n_loc * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    launch_permute_in(c, c->d_io, c->d_p);
+    HIPCHK(hipMemsetAsync(c->d_v, 0, (size_t)c->n_loc * sizeof(double), c->stream));
     launch_spmv_plain(c, c->d_vals, c->d_p, c->d_v);
-    HIPCHK(hipMemcpyAsync(y_host, c->d_v, (size_t)c->nv * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipGetLastError());
-    return 0;
+    return get_vector(c, c->d_v, y_host);
 }
 
 // ||F||_2 with a fixed summation order (device partials, host sum of <= 1024 values).
@@ -502,8 +527,8 @@ int shk_time_kernel(shk_ctx* ctx, int32_t phase, int32_t reps, double dt, double
     HIPCHK(hipEventSynchronize(b));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, a, b));
-    hipEventDestroy(a);
-    hipEventDestroy(b);
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
     c->profiling = was;
     *avg_ms = ms / reps;
     return 0;
@@ -512,8 +537,8 @@ int shk_time_kernel(shk_ctx* ctx, int32_t phase, int32_t reps, double dt, double
 int shk_plan_stats(shk_ctx* ctx, int64_t n[8]) {
     CHECK_CTX(ctx);
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
-    n[0] = c->nv; n[1] = c->ne; n[2] = c->nnz; n[3] = c->nblk; n[4] = (int64_t)c->plan.blk_cells.size();
-    n[5] = c->nsb; n[6] = c->device_bytes; n[7] = c->plan.max_row_len;
+    n[0] = c->n_own; n[1] = c->ne; n[2] = c->nnz; n[3] = c->nblk; n[4] = c->cells_staged;
+    n[5] = c->slots; n[6] = c->device_bytes; n[7] = c->plan.A.max_row_len;
     return 0;
 }
 

@@ -14,7 +14,6 @@ namespace shk {
 constexpr int kBlock = 256;        // threads per workgroup: 4 waves of 64
 constexpr int kMaxParts = 1024;    // upper bound of the reduction-partial arrays (= max grid)
 constexpr int kMaxQuad = 32;
-constexpr int kSpmvNnz = 2048;    // products one SpMV row block stages in LDS (16 KiB)
 
 // Constants of /root/reference/source/params.py:4-11 and derived products, passed by value
 // (kernarg segment -> scalar loads).
@@ -33,10 +32,10 @@ struct QuadArg {
     double phi0[kMaxQuad], phi1[kMaxQuad], phi2[kMaxQuad], w2[kMaxQuad];  // w2 = 2 * w
 };
 
-// Scalars of the BiCGStab recurrence.  Slots are written by block 0 of exactly one kernel and
-// read only by LATER kernels (visibility = kernel boundary on one stream).
+// Scalars of the BiCGStab recurrence.  A slot is written by block 0 of exactly one kernel and read
+// only by LATER kernels (visibility = kernel boundary on one stream).
 struct KrylovState {
-    double rho[2];      // (rhat, r) of iteration parity
+    double rho[2];      // (rhat, r) by iteration parity
     double alpha;
     double omega;
     double target2;     // squared stopping threshold
@@ -48,9 +47,17 @@ struct KrylovState {
     int its;            // iterations completed when done was set
 };
 
-struct Mesh {  // device pointers
+struct Mesh {  // device pointers, internal numbering
     const double2* xy;
     const int32_t* cells;  // 3*ne
+};
+
+// SELL-64 matrix of one level: slot(s, k, lane) = ptr[s] + 64 k + lane, row = 64 s + lane.
+struct DevSell {
+    int32_t n_rows, n_cols, nslice;
+    const int32_t* ptr;
+    const int32_t* col;
+    const uint8_t* rowlen;
 };
 
 struct AsmArgs {
@@ -59,12 +66,11 @@ struct AsmArgs {
     const uint8_t* bcflag;   // nullptr if no Dirichlet dofs
     double bc_value;
     double inv_rwg_dt;       // 1 / (rho_w g dt)
-    // plan
-    const int32_t *blk_row0, *blk_cellptr, *blk_cells, *incptr, *rowptr, *colidx;
+    DevSell A;
+    const int32_t *blk_slice0, *blk_cellptr, *blk_cells, *incptr;
     const uint16_t* inccode;
     int cells_max;           // LDS stride E
-    int rows_max;
-    int inc_max;
+    int slices_max;
     // outputs
     double* F;
     double* vals;
@@ -76,36 +82,40 @@ struct AsmArgs {
 struct Ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    int64_t nv = 0, ne = 0, nnz = 0;
+    int64_t n_own = 0, n_loc = 0, ne = 0, nnz = 0, slots = 0;
     shk_params params{};
     DevParams dp{};
     QuadArg quad{};
-    HostPlan plan;  // host copy kept for get_csr
+    HostPlan plan;
     int grid = 0;   // blocks used by grid-stride kernels == length of partial arrays
     // device memory
     std::vector<void*> allocs;
     int64_t device_bytes = 0;
     double2* d_xy = nullptr;
     int32_t* d_cells = nullptr;
-    double* f[SHK_FIELD_COUNT] = {nullptr};  // SHK_Q slot unused (qx/qy are separate)
+    int32_t* d_perm = nullptr;
+    double* d_io = nullptr;                   // 2*n_loc staging for permuted field I/O
+    double* f[SHK_FIELD_COUNT] = {nullptr};   // SHK_Q slot unused (qx/qy are separate)
     double *d_melt_tmp = nullptr, *d_b_tmp = nullptr, *d_m0 = nullptr;
     uint8_t* d_bcflag = nullptr;
     bool has_bc = false;
     double bc_value = 0.0;
-    int32_t *d_rowptr = nullptr, *d_colidx = nullptr, *d_diagpos = nullptr, *d_lastcell = nullptr;
-    int32_t *d_blk_row0 = nullptr, *d_blk_cellptr = nullptr, *d_blk_cells = nullptr, *d_incptr = nullptr;
+    int32_t *d_sell_ptr = nullptr, *d_sell_col = nullptr, *d_lastcell = nullptr;
+    uint8_t* d_rowlen = nullptr;
+    int32_t *d_blk_slice0 = nullptr, *d_blk_cellptr = nullptr, *d_blk_cells = nullptr, *d_incptr = nullptr;
     uint16_t* d_inccode = nullptr;
-    int32_t* d_sp_row0 = nullptr;
-    int nblk = 0, nsb = 0;
+    int nblk = 0;
+    int64_t cells_staged = 0;  // cells computed per assembly incl. those shared between blocks
     size_t asm_lds = 0;
     double *d_F = nullptr, *d_vals = nullptr, *d_vals_s = nullptr, *d_dinv = nullptr;
     // Krylov vectors
     double *d_r = nullptr, *d_rhat = nullptr, *d_p = nullptr, *d_v = nullptr, *d_s = nullptr, *d_t = nullptr,
            *d_y = nullptr;
-    double* d_part = nullptr;  // 6 arrays of kMaxParts
+    double* d_part = nullptr;  // 8 arrays of kMaxParts
     KrylovState* d_state = nullptr;
     KrylovState* h_state = nullptr;  // pinned, 2 slots
     double* h_part = nullptr;        // pinned, kMaxParts
+    hipEvent_t poll_ev[2] = {nullptr, nullptr};
     bool assembled = false;
     double assembled_dt = 0.0;
     // profiling
@@ -114,15 +124,18 @@ struct Ctx {
     std::vector<Ev> ev_pool;
     size_t ev_used = 0;
     shk_profile prof{};
+
+    DevSell sell() const {
+        return DevSell{(int32_t)n_own, (int32_t)n_loc, plan.A.nslice, d_sell_ptr, d_sell_col, d_rowlen};
+    }
 };
 
 // partial-array slots
-enum { P_RHO = 0, P_RR = 1, P_RHV = 2, P_TS = 3, P_TT = 4, P_AUX = 5 };
+enum { P_RR = 0, P_RHV = 1, P_TS = 2, P_TT = 3, P_RHT = 4, P_AUX = 5, P_COUNT = 8 };
 
 // launchers (shk_kernels.hip)
 hipError_t prepare_kernels(Ctx* c);
 void launch_assemble(Ctx* c, double dt);
-void launch_assemble_impl(Ctx* c, double dt, bool with_j);
 void launch_scale(Ctx* c);
 void launch_spmv_plain(Ctx* c, const double* vals, const double* x, double* y);
 void launch_norm2(Ctx* c, const double* x, double* partials);
@@ -130,8 +143,10 @@ void krylov_init(Ctx* c);
 void krylov_iteration(Ctx* c, int it);
 void launch_newton_update(Ctx* c, bool apply);
 void launch_update_explicit(Ctx* c, double dt);
-void launch_split_q(Ctx* c, const double* q_interleaved);
-void launch_join_q(Ctx* c, double* q_interleaved);
+void launch_permute_in(Ctx* c, const double* io, double* dst);            // dst[i] = io[perm[i]]
+void launch_permute_out(Ctx* c, const double* src, double* io);           // io[perm[i]] = src[i]
+void launch_split_q(Ctx* c, const double* io);                            // io interleaved, external order
+void launch_join_q(Ctx* c, double* io);
 
 struct PhaseTimer {  // RAII hipEvent pair when profiling is on
     Ctx* c;

@@ -6,7 +6,8 @@
 //                             atomic-free: each workgroup owns a row range, stages the element tensors
 //                             of every cell touching those rows in LDS, then writes each CSR value and
 //                             residual entry exactly once (deterministic summation order).
-//   k_spmv          CSR-stream SpMV with the BiCGStab dot products fused into the row epilogue.
+//   k_spmv          SELL-64 SpMV (one row per lane, coalesced column-major slices, row sums in
+//                   registers) with the BiCGStab dot products fused into the row epilogue.
 //   k_bicg_*        fused vector updates of right-Jacobi-preconditioned BiCGStab; scalars are
 //                   re-derived in every workgroup from per-workgroup partial sums, so there is no
 //                   host sync, no atomics, and results are bitwise reproducible.
@@ -51,21 +52,21 @@ __global__ __launch_bounds__(kBlock) void k_assemble(const AsmArgs a) {
     const int E = a.cells_max;
     double* et = reinterpret_cast<double*>(smem);                 // [12][E] element tensors
     int* cv = reinterpret_cast<int*>(et + 12 * (size_t)E);       // [3][E] cell vertex ids
-    int* rp = cv + 3 * E;                                         // [rows_max+1] rowptr of owned rows
-    int* ip = rp + (a.rows_max + 1);                              // [rows_max+1] incptr of owned rows
-    uint16_t* ic = reinterpret_cast<uint16_t*>(ip + (a.rows_max + 1));  // incidence codes
+    int* sp = cv + 3 * E;                                         // [slices_max+1] SELL ptr of owned slices
+    int* ip = sp + (a.slices_max + 1);                            // [rows+1] incptr of owned rows
+    uint16_t* ic = reinterpret_cast<uint16_t*>(ip + (a.slices_max * kSlice + 1));  // incidence codes
 
     const int blk = blockIdx.x;
     const int tid = threadIdx.x;
-    const int r0 = a.blk_row0[blk], r1 = a.blk_row0[blk + 1];
+    const int s0 = a.blk_slice0[blk], ns = a.blk_slice0[blk + 1] - s0;
+    const int r0 = s0 * kSlice;
+    const int r1 = min(a.A.n_rows, (s0 + ns) * kSlice);
     const int nrows = r1 - r0;
     const int c0 = a.blk_cellptr[blk], ncell = a.blk_cellptr[blk + 1] - c0;
     const DevParams& p = a.p;
 
-    for (int i = tid; i <= nrows; i += kBlock) {
-        rp[i] = a.rowptr[r0 + i];
-        ip[i] = a.incptr[r0 + i];
-    }
+    for (int i = tid; i <= ns; i += kBlock) sp[i] = a.A.ptr[s0 + i];
+    for (int i = tid; i <= nrows; i += kBlock) ip[i] = a.incptr[r0 + i];
     const int ip0 = a.incptr[r0], ninc = a.incptr[r1] - ip0;
     for (int i = tid; i < ninc; i += kBlock) ic[i] = a.inccode[ip0 + i];
 
@@ -199,31 +200,33 @@ __global__ __launch_bounds__(kBlock) void k_assemble(const AsmArgs a) {
     }
     __syncthreads();
 
-    // ---- phase 2a: one thread per stored Jacobian entry of the owned rows ----
+    // ---- phase 2a: one thread per SELL slot of the owned slices ----
     if (WITH_J) {
-        const int n0 = rp[0], n1 = rp[nrows];
+        const int n0 = sp[0], n1 = sp[ns];
         for (int s = n0 + tid; s < n1; s += kBlock) {
-            int lo = 0, hi = nrows;
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (rp[mid] <= s) lo = mid; else hi = mid;
-            }
-            const int v = r0 + lo;
-            const int u = a.colidx[s];
+            int j = 0;
+            while (j + 1 < ns && sp[j + 1] <= s) ++j;
+            const int off = s - sp[j];
+            const int k = off >> 6, lane = off & 63;
+            const int v = (s0 + j) * kSlice + lane;
             double sum = 0.0;
-            const int kb = ip[lo] - ip0, ke = ip[lo + 1] - ip0;
-            for (int k = kb; k < ke; ++k) {  // ascending cell id: fixed summation order
-                const int code = ic[k];
-                const int t = code >> 2, li = code & 3;
-                const int j = (cv[t] == u) ? 0 : (cv[E + t] == u) ? 1 : (cv[2 * E + t] == u) ? 2 : -1;
-                if (j >= 0) sum += et[(li * 3 + j) * E + t];
+            if (v < a.A.n_rows && k < (int)a.A.rowlen[v]) {
+                const int u = a.A.col[s];
+                const int i = v - r0;
+                const int kb = ip[i] - ip0, ke = ip[i + 1] - ip0;
+                for (int q = kb; q < ke; ++q) {  // ascending cell id: fixed summation order
+                    const int code = ic[q];
+                    const int t = code >> 2, li = code & 3;
+                    const int jj = (cv[t] == u) ? 0 : (cv[E + t] == u) ? 1 : (cv[2 * E + t] == u) ? 2 : -1;
+                    if (jj >= 0) sum += et[(li * 3 + jj) * E + t];
+                }
+                if (a.bcflag) {  // Dirichlet rows and columns zeroed, unit diagonal
+                    const bool bv = a.bcflag[v], bu = a.bcflag[u];
+                    if (bv | bu) sum = (u == v && bv) ? 1.0 : 0.0;
+                }
+                if (k == 0) a.dinv[v] = (sum != 0.0) ? 1.0 / sum : 1.0;  // the diagonal is stored first
             }
-            if (a.bcflag) {  // Dirichlet rows and columns zeroed, unit diagonal
-                const bool bv = a.bcflag[v], bu = a.bcflag[u];
-                if (bv | bu) sum = (u == v && bv) ? 1.0 : 0.0;
-            }
-            a.vals[s] = sum;
-            if (u == v) a.dinv[v] = (sum != 0.0) ? 1.0 / sum : 1.0;
+            a.vals[s] = sum;  // padding slots hold exact zeros
         }
     }
     // ---- phase 2b: one thread per owned residual row ----
@@ -231,8 +234,8 @@ __global__ __launch_bounds__(kBlock) void k_assemble(const AsmArgs a) {
         const int v = r0 + i;
         double sum = 0.0;
         const int kb = ip[i] - ip0, ke = ip[i + 1] - ip0;
-        for (int k = kb; k < ke; ++k) {
-            const int code = ic[k];
+        for (int q = kb; q < ke; ++q) {
+            const int code = ic[q];
             sum += et[(9 + (code & 3)) * E + (code >> 2)];
         }
         if (a.bcflag && a.bcflag[v]) sum = a.N[v] - a.bc_value;  // set_bc(b, bcs, x, -1)
@@ -240,8 +243,7 @@ __global__ __launch_bounds__(kBlock) void k_assemble(const AsmArgs a) {
     }
 }
 
-void launch_assemble_impl(Ctx* c, double dt, bool with_j) {
-    AsmArgs a;
+static void fill_asm_args(Ctx* c, double dt, AsmArgs& a) {
     a.m.xy = c->d_xy;
     a.m.cells = c->d_cells;
     a.N = c->f[SHK_N]; a.N_n = c->f[SHK_N_N]; a.b = c->f[SHK_B]; a.qx = c->f[SHK_QX]; a.qy = c->f[SHK_QY];
@@ -250,89 +252,129 @@ void launch_assemble_impl(Ctx* c, double dt, bool with_j) {
     a.bcflag = c->has_bc ? c->d_bcflag : nullptr;
     a.bc_value = c->bc_value;
     a.inv_rwg_dt = 1.0 / (c->dp.rwg * dt);
-    a.blk_row0 = c->d_blk_row0; a.blk_cellptr = c->d_blk_cellptr; a.blk_cells = c->d_blk_cells;
-    a.incptr = c->d_incptr; a.rowptr = c->d_rowptr; a.colidx = c->d_colidx; a.inccode = c->d_inccode;
-    a.cells_max = c->plan.cells_max; a.rows_max = c->plan.rows_max; a.inc_max = c->plan.max_inc_per_block;
+    a.A = c->sell();
+    a.blk_slice0 = c->d_blk_slice0; a.blk_cellptr = c->d_blk_cellptr; a.blk_cells = c->d_blk_cells;
+    a.incptr = c->d_incptr; a.inccode = c->d_inccode;
+    a.cells_max = c->plan.cells_max; a.slices_max = c->plan.slices_max;
     a.F = c->d_F; a.vals = c->d_vals; a.dinv = c->d_dinv;
     a.p = c->dp;
     a.quad = c->quad;
-    PhaseTimer t(c, SHK_PH_ASSEMBLE);
-    if (with_j)
-        hipLaunchKernelGGL(k_assemble<true>, dim3(c->nblk), dim3(kBlock), c->asm_lds, c->stream, a);
-    else
-        hipLaunchKernelGGL(k_assemble<false>, dim3(c->nblk), dim3(kBlock), c->asm_lds, c->stream, a);
 }
 
-void launch_assemble(Ctx* c, double dt) { launch_assemble_impl(c, dt, true); }
+void launch_assemble(Ctx* c, double dt) {
+    AsmArgs a;
+    fill_asm_args(c, dt, a);
+    PhaseTimer t(c, SHK_PH_ASSEMBLE);
+    hipLaunchKernelGGL(k_assemble<true>, dim3(c->nblk), dim3(kBlock), c->asm_lds, c->stream, a);
+}
 
 // Dynamic LDS above 64 KiB has to be requested per kernel.
 hipError_t prepare_kernels(Ctx* c) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble<true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->asm_lds);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble<false>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble<true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->asm_lds);
 }
 
 // A' = A D^-1 (right Jacobi preconditioning folded into the matrix once per Newton iteration)
-__global__ __launch_bounds__(kBlock) void k_scale(int64_t nnz, const int32_t* __restrict__ colidx,
+__global__ __launch_bounds__(kBlock) void k_scale(int64_t slots, const int32_t* __restrict__ col,
                                                   const double* __restrict__ vals,
                                                   const double* __restrict__ dinv, double* __restrict__ out) {
-    for (int64_t s = blockIdx.x * (int64_t)kBlock + threadIdx.x; s < nnz; s += (int64_t)gridDim.x * kBlock)
-        out[s] = vals[s] * dinv[colidx[s]];
+    for (int64_t s = blockIdx.x * (int64_t)kBlock + threadIdx.x; s < slots; s += (int64_t)gridDim.x * kBlock)
+        out[s] = vals[s] * dinv[col[s]];
 }
 
 void launch_scale(Ctx* c) {
     PhaseTimer t(c, SHK_PH_OTHER);
-    int g = (int)std::min<int64_t>((c->nnz + kBlock - 1) / kBlock, 8192);
-    hipLaunchKernelGGL(k_scale, dim3(g), dim3(kBlock), 0, c->stream, c->nnz, c->d_colidx, c->d_vals, c->d_dinv,
+    int g = (int)std::min<int64_t>((c->slots + kBlock - 1) / kBlock, 8192);
+    hipLaunchKernelGGL(k_scale, dim3(g), dim3(kBlock), 0, c->stream, c->slots, c->d_sell_col, c->d_vals, c->d_dinv,
                        c->d_vals_s);
 }
 
-// ------------------------------------------------------------------ SpMV (CSR-stream)
-// MODE 0: y = A x.   MODE 1: + partial (w . y) -> pa.   MODE 2: + partials (y . x_own) -> pa, (y . y) -> pb.
-template <int MODE, int NNZB>
-__global__ __launch_bounds__(kBlock) void k_spmv(const int32_t* __restrict__ sp_row0, int nsb,
-                                                 const int32_t* __restrict__ rowptr,
-                                                 const int32_t* __restrict__ colidx,
-                                                 const double* __restrict__ vals, const double* __restrict__ x,
-                                                 double* __restrict__ y, const double* __restrict__ w,
-                                                 double* __restrict__ pa, double* __restrict__ pb,
-                                                 const KrylovState* __restrict__ st) {
-    __shared__ double prod[NNZB];
+// ------------------------------------------------------------------ SpMV (SELL-64)
+// One wavefront per slice, one row per lane; the slice is stored column-major so every load of
+// values / column indices is a contiguous 512 B / 256 B wave access and the row sum never leaves
+// its register.
+//   MODE 0: y = A x
+//   MODE 1: BiCGStab first product  v = A p, partial (rhat . v); its prologue is the convergence test
+//   MODE 2: BiCGStab second product t = A s, partials (t . s), (t . t), (rhat . t)
+struct SpmvArgs {
+    DevSell A;
+    const double* vals;
+    const double* x;
+    double* y;
+    const double* rhat;
+    double* part;            // partial arrays (MODE 1, 2)
+    KrylovState* st;
+    int it, max_it, np;
+    double rtol2, atol2;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_spmv(const SpmvArgs a) {
     __shared__ double sh4[4];
-    if (MODE != 0 && st->done) return;
     const int tid = threadIdx.x;
-    double da = 0.0, db = 0.0;
-    for (int sb = blockIdx.x; sb < nsb; sb += gridDim.x) {
-        const int r0 = sp_row0[sb], r1 = sp_row0[sb + 1];
-        const int n0 = rowptr[r0], n1 = rowptr[r1];
-        for (int s = n0 + tid; s < n1; s += kBlock) prod[s - n0] = vals[s] * x[colidx[s]];
-        __syncthreads();
-        for (int r = r0 + tid; r < r1; r += kBlock) {
-            const int a = rowptr[r] - n0, b = rowptr[r + 1] - n0;
-            double sum = 0.0;
-            for (int k = a; k < b; ++k) sum += prod[k];
-            y[r] = sum;
-            if (MODE == 1) da += w[r] * sum;
-            if (MODE == 2) { da += sum * x[r]; db += sum * sum; }
-        }
-        __syncthreads();
+    if (MODE != 0) {
+        if (a.st->done) return;
     }
-    if (MODE >= 1) {
-        const double ra = block_sum(da, sh4);
-        if (tid == 0) pa[blockIdx.x] = ra;
+    if (MODE == 1) {
+        // iteration `it` starts here: ||r||^2 of the previous update decides whether to go on
+        const double rr = reduce_partials(a.part + P_RR * kMaxParts, a.np, sh4);
+        const double target2 = (a.it == 0) ? fmax(a.rtol2 * rr, a.atol2) : a.st->target2;
+        const bool lead = (blockIdx.x == 0 && tid == 0);
+        int stop = 0, conv = 0;
+        if (!(rr > target2)) { stop = 1; conv = (rr <= target2); }  // also stops on NaN
+        else if (a.it >= a.max_it) stop = 1;
+        if (lead && a.it == 0) { a.st->target2 = target2; a.st->rhs2 = rr; a.st->rho[0] = rr; }
+        if (stop) {
+            if (lead) { a.st->converged = conv; a.st->its = a.it; a.st->rnorm2 = rr; a.st->done = 1; }
+            return;
+        }
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0;
+    for (int s = blockIdx.x * (kBlock / kSlice) + wave; s < a.A.nslice; s += gridDim.x * (kBlock / kSlice)) {
+        const int base = __builtin_amdgcn_readfirstlane(a.A.ptr[s]);
+        const int width = (__builtin_amdgcn_readfirstlane(a.A.ptr[s + 1]) - base) >> 6;
+        const double* __restrict__ vp = a.vals + base + lane;
+        const int32_t* __restrict__ cp = a.A.col + base + lane;
+        double sum = 0.0;
+#pragma unroll 4
+        for (int k = 0; k < width; ++k) sum += vp[k * kSlice] * a.x[cp[k * kSlice]];
+        const int row = s * kSlice + lane;
+        if (row < a.A.n_rows) {
+            a.y[row] = sum;
+            if (MODE == 1) d0 += a.rhat[row] * sum;
+            if (MODE == 2) { d0 += sum * a.x[row]; d1 += sum * sum; d2 += a.rhat[row] * sum; }
+        }
+    }
+    if (MODE == 1) {
+        d0 = block_sum(d0, sh4);
+        if (tid == 0) a.part[P_RHV * kMaxParts + blockIdx.x] = d0;
     }
     if (MODE == 2) {
-        const double rb = block_sum(db, sh4);
-        if (tid == 0) pb[blockIdx.x] = rb;
+        d0 = block_sum(d0, sh4);
+        d1 = block_sum(d1, sh4);
+        d2 = block_sum(d2, sh4);
+        if (tid == 0) {
+            a.part[P_TS * kMaxParts + blockIdx.x] = d0;
+            a.part[P_TT * kMaxParts + blockIdx.x] = d1;
+            a.part[P_RHT * kMaxParts + blockIdx.x] = d2;
+        }
     }
+}
+
+static SpmvArgs spmv_args(Ctx* c, const double* vals, const double* x, double* y, int it) {
+    SpmvArgs a;
+    a.A = c->sell();
+    a.vals = vals; a.x = x; a.y = y; a.rhat = c->d_rhat; a.part = c->d_part; a.st = c->d_state;
+    a.it = it; a.max_it = c->params.krylov_max_it; a.np = c->grid;
+    a.rtol2 = c->params.krylov_rtol * c->params.krylov_rtol;
+    a.atol2 = c->params.krylov_atol * c->params.krylov_atol;
+    return a;
 }
 
 void launch_spmv_plain(Ctx* c, const double* vals, const double* x, double* y) {
     PhaseTimer t(c, SHK_PH_SPMV);
-    hipLaunchKernelGGL((k_spmv<0, kSpmvNnz>), dim3(c->grid), dim3(kBlock), 0, c->stream, c->d_sp_row0, c->nsb,
-                       c->d_rowptr, c->d_colidx, vals, x, y, nullptr, nullptr, nullptr, c->d_state);
+    hipLaunchKernelGGL(k_spmv<0>, dim3(c->grid), dim3(kBlock), 0, c->stream, spmv_args(c, vals, x, y, 0));
 }
 
 // ------------------------------------------------------------------ vector kernels
@@ -347,68 +389,40 @@ __global__ __launch_bounds__(kBlock) void k_norm2(int64_t n, const double* __res
 
 void launch_norm2(Ctx* c, const double* x, double* partials) {
     PhaseTimer t(c, SHK_PH_OTHER);
-    hipLaunchKernelGGL(k_norm2, dim3(c->grid), dim3(kBlock), 0, c->stream, c->nv, x, partials);
+    hipLaunchKernelGGL(k_norm2, dim3(c->grid), dim3(kBlock), 0, c->stream, c->n_own, x, partials);
 }
 
-// r = rhat = rhs, p = v = y = 0, partials of ||rhs||^2; block 0 resets the recurrence scalars.
+// Merged-reduction BiCGStab (right preconditioning folded into A' = A D^-1), x0 = 0:
+//   init      r = rhat = p = rhs, y = 0, partial ||rhs||^2
+//   spmv<1>   [stop test on ||r||^2]  v = A' p, (rhat.v)
+//   k_bicg_s  alpha = rho / (rhat.v);  s = r - alpha v
+//   spmv<2>   t = A' s, (t.s), (t.t), (rhat.t)
+//   k_bicg_u  omega = (t.s)/(t.t); rho' = -omega (rhat.t)   [(rhat.s) = 0 by construction]
+//             beta = (rho'/rho)(alpha/omega) = -alpha (rhat.t)/rho
+//             y += alpha p + omega s;  r = s - omega t;  p = r + beta (p - omega v);  partial ||r||^2
+// Two reduction points per iteration instead of three, four kernels instead of five.
 __global__ __launch_bounds__(kBlock) void k_bicg_init(int64_t n, const double* __restrict__ rhs,
                                                       double* __restrict__ r, double* __restrict__ rhat,
-                                                      double* __restrict__ p, double* __restrict__ v,
-                                                      double* __restrict__ y, double* __restrict__ part,
-                                                      KrylovState* __restrict__ st) {
+                                                      double* __restrict__ p, double* __restrict__ y,
+                                                      double* __restrict__ part, KrylovState* __restrict__ st) {
     __shared__ double sh4[4];
     double a = 0.0;
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         const double f = rhs[i];
-        r[i] = f; rhat[i] = f; p[i] = 0.0; v[i] = 0.0; y[i] = 0.0;
+        r[i] = f; rhat[i] = f; p[i] = f; y[i] = 0.0;
         a += f * f;
     }
     a = block_sum(a, sh4);
     if (threadIdx.x == 0) {
-        part[P_RHO * kMaxParts + blockIdx.x] = a;
         part[P_RR * kMaxParts + blockIdx.x] = a;
         if (blockIdx.x == 0) {
-            st->rho[0] = 1.0; st->rho[1] = 1.0; st->alpha = 1.0; st->omega = 1.0;
+            st->rho[0] = 0.0; st->rho[1] = 0.0; st->alpha = 0.0; st->omega = 0.0;
             st->target2 = 0.0; st->rnorm2 = 0.0; st->rhs2 = 0.0;
             st->done = 0; st->converged = 0; st->breakdown = 0; st->its = 0;
         }
     }
 }
 
-// Start of iteration `it`: convergence test on ||r||, then p = r + beta (p - omega v).
-__global__ __launch_bounds__(kBlock) void k_bicg_p(int64_t n, int it, int max_it, double rtol2, double atol2,
-                                                   int np, const double* __restrict__ part,
-                                                   const double* __restrict__ r, const double* __restrict__ v,
-                                                   double* __restrict__ p, KrylovState* __restrict__ st) {
-    __shared__ double sh4[4];
-    if (st->done) return;
-    const double rho_new = reduce_partials(part + P_RHO * kMaxParts, np, sh4);
-    const double rr = reduce_partials(part + P_RR * kMaxParts, np, sh4);
-    const double target2 = (it == 0) ? fmax(rtol2 * rr, atol2) : st->target2;
-    const double rho_old = st->rho[(it + 1) & 1], alpha = st->alpha, omega = st->omega;
-    const double beta = (rho_new / rho_old) * (alpha / omega);
-    const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
-    int stop = 0, conv = 0, brk = 0;
-    if (!(rr > target2)) { stop = 1; conv = (rr <= target2); }   // also stops on NaN
-    else if (it >= max_it) stop = 1;
-    else if (!isfinite(beta)) { stop = 1; brk = 1; }
-    if (stop) {
-        if (lead) {
-            st->converged = conv; st->breakdown = brk; st->its = it; st->rnorm2 = rr;
-            if (it == 0) { st->target2 = target2; st->rhs2 = rr; }
-            st->done = 1;
-        }
-        return;
-    }
-    if (lead) {
-        st->rho[it & 1] = rho_new;
-        if (it == 0) { st->target2 = target2; st->rhs2 = rr; }
-    }
-    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
-        p[i] = r[i] + beta * (p[i] - omega * v[i]);
-}
-
-// alpha = rho / (rhat . v); s = r - alpha v
 __global__ __launch_bounds__(kBlock) void k_bicg_s(int64_t n, int it, int np, const double* __restrict__ part,
                                                    const double* __restrict__ r, const double* __restrict__ v,
                                                    double* __restrict__ s, KrylovState* __restrict__ st) {
@@ -426,72 +440,72 @@ __global__ __launch_bounds__(kBlock) void k_bicg_s(int64_t n, int it, int np, co
         s[i] = r[i] - alpha * v[i];
 }
 
-// omega = (t.s)/(t.t); y += alpha p + omega s; r = s - omega t; partials (rhat.r), (r.r)
-__global__ __launch_bounds__(kBlock) void k_bicg_xr(int64_t n, int np, double* __restrict__ part,
-                                                    const double* __restrict__ p, const double* __restrict__ s,
-                                                    const double* __restrict__ t, const double* __restrict__ rhat,
-                                                    double* __restrict__ y, double* __restrict__ r,
-                                                    KrylovState* __restrict__ st) {
+// Closes iteration `it` (it >= 0) and prepares p for iteration it+1.
+__global__ __launch_bounds__(kBlock) void k_bicg_u(int64_t n, int it, int np, double* __restrict__ part,
+                                                   const double* __restrict__ s, const double* __restrict__ t,
+                                                   const double* __restrict__ v, double* __restrict__ p,
+                                                   double* __restrict__ y, double* __restrict__ r,
+                                                   KrylovState* __restrict__ st) {
     __shared__ double sh4[4];
     if (st->done) return;
-    const double ts = reduce_partials(part + P_TS * kMaxParts, np, sh4);
-    const double tt = reduce_partials(part + P_TT * kMaxParts, np, sh4);
+    double ts = 0.0, tt = 0.0, rht = 0.0;
+    for (int i = threadIdx.x; i < np; i += kBlock) {
+        ts += part[P_TS * kMaxParts + i];
+        tt += part[P_TT * kMaxParts + i];
+        rht += part[P_RHT * kMaxParts + i];
+    }
+    ts = block_sum(ts, sh4);
+    tt = block_sum(tt, sh4);
+    rht = block_sum(rht, sh4);
+    const double alpha = st->alpha, rho = st->rho[it & 1];
     const double omega = (tt > 0.0) ? ts / tt : 0.0;
-    const double alpha = st->alpha;
-    if (blockIdx.x == 0 && threadIdx.x == 0) st->omega = omega;
-    double a = 0.0, b = 0.0;
+    const double rho_new = -omega * rht;
+    const double beta = -alpha * rht / rho;
+    const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
+    if (!isfinite(beta) || !isfinite(omega)) {
+        if (lead) { st->breakdown = 1; st->converged = 0; st->its = it; st->done = 1; }
+        return;
+    }
+    if (lead) { st->omega = omega; st->rho[(it + 1) & 1] = rho_new; }
+    double a = 0.0;
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        const double si = s[i];
-        y[i] += alpha * p[i] + omega * si;
+        const double si = s[i], pi = p[i];
+        y[i] += alpha * pi + omega * si;
         const double ri = si - omega * t[i];
         r[i] = ri;
-        a += rhat[i] * ri;
-        b += ri * ri;
+        p[i] = ri + beta * (pi - omega * v[i]);
+        a += ri * ri;
     }
     a = block_sum(a, sh4);
-    b = block_sum(b, sh4);
-    if (threadIdx.x == 0) {
-        part[P_RHO * kMaxParts + blockIdx.x] = a;
-        part[P_RR * kMaxParts + blockIdx.x] = b;
-    }
+    if (threadIdx.x == 0) part[P_RR * kMaxParts + blockIdx.x] = a;
 }
 
 void krylov_init(Ctx* c) {
     PhaseTimer t(c, SHK_PH_VECTOR);
-    hipLaunchKernelGGL(k_bicg_init, dim3(c->grid), dim3(kBlock), 0, c->stream, c->nv, c->d_F, c->d_r, c->d_rhat,
-                       c->d_p, c->d_v, c->d_y, c->d_part, c->d_state);
+    hipLaunchKernelGGL(k_bicg_init, dim3(c->grid), dim3(kBlock), 0, c->stream, c->n_own, c->d_F, c->d_r, c->d_rhat,
+                       c->d_p, c->d_y, c->d_part, c->d_state);
 }
 
 void krylov_iteration(Ctx* c, int it) {
     const dim3 g(c->grid), b(kBlock);
-    const double rt = c->params.krylov_rtol, at = c->params.krylov_atol;
     double* part = c->d_part;
     {
-        PhaseTimer t(c, SHK_PH_VECTOR);
-        hipLaunchKernelGGL(k_bicg_p, g, b, 0, c->stream, c->nv, it, c->params.krylov_max_it, rt * rt, at * at,
-                           c->grid, part, c->d_r, c->d_v, c->d_p, c->d_state);
-    }
-    {
         PhaseTimer t(c, SHK_PH_SPMV);
-        hipLaunchKernelGGL((k_spmv<1, kSpmvNnz>), g, b, 0, c->stream, c->d_sp_row0, c->nsb, c->d_rowptr,
-                           c->d_colidx, c->d_vals_s, c->d_p, c->d_v, c->d_rhat, part + P_RHV * kMaxParts, nullptr,
-                           c->d_state);
+        hipLaunchKernelGGL(k_spmv<1>, g, b, 0, c->stream, spmv_args(c, c->d_vals_s, c->d_p, c->d_v, it));
     }
     {
         PhaseTimer t(c, SHK_PH_VECTOR);
-        hipLaunchKernelGGL(k_bicg_s, g, b, 0, c->stream, c->nv, it, c->grid, part, c->d_r, c->d_v, c->d_s,
+        hipLaunchKernelGGL(k_bicg_s, g, b, 0, c->stream, c->n_own, it, c->grid, part, c->d_r, c->d_v, c->d_s,
                            c->d_state);
     }
     {
         PhaseTimer t(c, SHK_PH_SPMV);
-        hipLaunchKernelGGL((k_spmv<2, kSpmvNnz>), g, b, 0, c->stream, c->d_sp_row0, c->nsb, c->d_rowptr,
-                           c->d_colidx, c->d_vals_s, c->d_s, c->d_t, nullptr, part + P_TS * kMaxParts,
-                           part + P_TT * kMaxParts, c->d_state);
+        hipLaunchKernelGGL(k_spmv<2>, g, b, 0, c->stream, spmv_args(c, c->d_vals_s, c->d_s, c->d_t, it));
     }
     {
         PhaseTimer t(c, SHK_PH_VECTOR);
-        hipLaunchKernelGGL(k_bicg_xr, g, b, 0, c->stream, c->nv, c->grid, part, c->d_p, c->d_s, c->d_t, c->d_rhat,
-                           c->d_y, c->d_r, c->d_state);
+        hipLaunchKernelGGL(k_bicg_u, g, b, 0, c->stream, c->n_own, it, c->grid, part, c->d_s, c->d_t, c->d_v,
+                           c->d_p, c->d_y, c->d_r, c->d_state);
     }
 }
 
@@ -509,7 +523,7 @@ __global__ __launch_bounds__(kBlock) void k_newton_update(int64_t n, double rela
 
 void launch_newton_update(Ctx* c, bool apply) {
     PhaseTimer t(c, SHK_PH_OTHER);
-    hipLaunchKernelGGL(k_newton_update, dim3(c->grid), dim3(kBlock), 0, c->stream, c->nv, c->params.newton_relax,
+    hipLaunchKernelGGL(k_newton_update, dim3(c->grid), dim3(kBlock), 0, c->stream, c->n_own, c->params.newton_relax,
                        apply ? 1 : 0, c->d_y, c->d_dinv, c->f[SHK_DX], c->f[SHK_N]);
 }
 
@@ -596,8 +610,8 @@ void launch_update_explicit(Ctx* c, double dt) {
     a.b = c->f[SHK_B]; a.qx = c->f[SHK_QX]; a.qy = c->f[SHK_QY]; a.melt_n = c->f[SHK_MELT_N];
     a.N_n = c->f[SHK_N_N];
     a.melt_tmp = c->d_melt_tmp; a.b_tmp = c->d_b_tmp; a.m0 = c->d_m0;
-    a.dt = dt; a.nv = c->nv; a.p = c->dp;
-    int g = (int)std::min<int64_t>((c->nv + kBlock - 1) / kBlock, 4096);
+    a.dt = dt; a.nv = c->n_own; a.p = c->dp;
+    int g = (int)std::min<int64_t>((c->n_own + kBlock - 1) / kBlock, 4096);
     {
         PhaseTimer t(c, SHK_PH_UPDATE);
         hipLaunchKernelGGL(k_update_a, dim3(g), dim3(kBlock), 0, c->stream, a);
@@ -610,22 +624,45 @@ void launch_update_explicit(Ctx* c, double dt) {
     std::swap(c->f[SHK_B], c->d_b_tmp);
 }
 
-// ------------------------------------------------------------------ q layout helpers
-__global__ void k_split_q(int64_t n, const double* __restrict__ q, double* __restrict__ qx, double* __restrict__ qy) {
+// ------------------------------------------------------------------ field I/O in the caller's numbering
+__global__ void k_permute_in(int64_t n, const int32_t* __restrict__ perm, const double* __restrict__ io,
+                             double* __restrict__ dst) {
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        dst[i] = io[perm[i]];
+}
+__global__ void k_permute_out(int64_t n, const int32_t* __restrict__ perm, const double* __restrict__ src,
+                              double* __restrict__ io) {
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        io[perm[i]] = src[i];
+}
+__global__ void k_split_q(int64_t n, const int32_t* __restrict__ perm, const double* __restrict__ q,
+                          double* __restrict__ qx, double* __restrict__ qy) {
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        qx[i] = q[2 * i]; qy[i] = q[2 * i + 1];
+        const int64_t e = perm[i];
+        qx[i] = q[2 * e]; qy[i] = q[2 * e + 1];
     }
 }
-__global__ void k_join_q(int64_t n, const double* __restrict__ qx, const double* __restrict__ qy, double* __restrict__ q) {
+__global__ void k_join_q(int64_t n, const int32_t* __restrict__ perm, const double* __restrict__ qx,
+                         const double* __restrict__ qy, double* __restrict__ q) {
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        q[2 * i] = qx[i]; q[2 * i + 1] = qy[i];
+        const int64_t e = perm[i];
+        q[2 * e] = qx[i]; q[2 * e + 1] = qy[i];
     }
 }
-void launch_split_q(Ctx* c, const double* q) {
-    hipLaunchKernelGGL(k_split_q, dim3(c->grid), dim3(kBlock), 0, c->stream, c->nv, q, c->f[SHK_QX], c->f[SHK_QY]);
+static int io_grid(Ctx* c) { return (int)std::min<int64_t>((c->n_loc + kBlock - 1) / kBlock, 4096); }
+void launch_permute_in(Ctx* c, const double* io, double* dst) {
+    hipLaunchKernelGGL(k_permute_in, dim3(io_grid(c)), dim3(kBlock), 0, c->stream, c->n_loc, c->d_perm, io, dst);
 }
-void launch_join_q(Ctx* c, double* q) {
-    hipLaunchKernelGGL(k_join_q, dim3(c->grid), dim3(kBlock), 0, c->stream, c->nv, c->f[SHK_QX], c->f[SHK_QY], q);
+void launch_permute_out(Ctx* c, const double* src, double* io) {
+    hipLaunchKernelGGL(k_permute_out, dim3(io_grid(c)), dim3(kBlock), 0, c->stream, c->n_loc, c->d_perm, src, io);
+}
+void launch_split_q(Ctx* c, const double* io) {
+    hipLaunchKernelGGL(k_split_q, dim3(io_grid(c)), dim3(kBlock), 0, c->stream, c->n_loc, c->d_perm, io,
+                       c->f[SHK_QX], c->f[SHK_QY]);
+}
+void launch_join_q(Ctx* c, double* io) {
+    hipLaunchKernelGGL(k_join_q, dim3(io_grid(c)), dim3(kBlock), 0, c->stream, c->n_loc, c->d_perm, c->f[SHK_QX],
+                       c->f[SHK_QY], io);
 }
 
 // ------------------------------------------------------------------ profiling
@@ -633,16 +670,16 @@ PhaseTimer::PhaseTimer(Ctx* c_, int phase) : c(c_) {
     if (!c->profiling) return;
     if (c->ev_used == c->ev_pool.size()) {
         Ctx::Ev e;
-        hipEventCreate(&e.a);
-        hipEventCreate(&e.b);
+        (void)hipEventCreate(&e.a);
+        (void)hipEventCreate(&e.b);
         c->ev_pool.push_back(e);
     }
     idx = (int)c->ev_used++;
     c->ev_pool[idx].phase = phase;
-    hipEventRecord(c->ev_pool[idx].a, c->stream);
+    (void)hipEventRecord(c->ev_pool[idx].a, c->stream);
 }
 PhaseTimer::~PhaseTimer() {
-    if (idx >= 0) hipEventRecord(c->ev_pool[idx].b, c->stream);
+    if (idx >= 0) (void)hipEventRecord(c->ev_pool[idx].b, c->stream);
 }
 
 }  // namespace shk

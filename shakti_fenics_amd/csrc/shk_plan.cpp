@@ -1,155 +1,246 @@
 // Static plan construction on the host (see shk_plan.h).  Everything here is O(ne) with small
-// constants; it runs once in shk_create().
+// constants and runs once in shk_create().
 #include "shk_plan.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
+#include <numeric>
 
 namespace shk {
 
-std::string build_plan(int64_t nv, int64_t ne, const int32_t* cells, const PlanOptions& opt, HostPlan& P) {
-    if (nv <= 0 || ne <= 0) return "empty mesh";
-    if (nv > INT32_MAX / 2 || ne > INT32_MAX / 4) return "mesh too large for int32 indexing";
-    P.nv = nv;
-    P.ne = ne;
-    for (int64_t i = 0; i < 3 * ne; ++i)
-        if (cells[i] < 0 || cells[i] >= nv) return "cell references a vertex outside [0, nv)";
+static inline uint64_t spread21(uint64_t v) {  // bit k -> bit 2k for the low 21 bits... (32 handled)
+    v &= 0xFFFFFFFFull;
+    v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
+    v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
+    v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    v = (v | (v << 2)) & 0x3333333333333333ull;
+    v = (v | (v << 1)) & 0x5555555555555555ull;
+    return v;
+}
 
-    // ---- vertex -> incident cells (ascending cell id) ----
-    std::vector<int32_t> v2c_ptr(nv + 1, 0);
-    for (int64_t i = 0; i < 3 * ne; ++i) v2c_ptr[cells[i] + 1]++;
-    for (int64_t v = 0; v < nv; ++v) {
-        if (v2c_ptr[v + 1] == 0) return "mesh has a vertex that belongs to no cell";
-        v2c_ptr[v + 1] += v2c_ptr[v];
+// sorted unique vertex set of the cells incident to v, diagonal first
+static int row_columns(int32_t v, const int32_t* v2c_ptr, const int32_t* v2c, const int32_t* cells,
+                       std::vector<int32_t>& tmp) {
+    tmp.clear();
+    for (int32_t k = v2c_ptr[v]; k < v2c_ptr[v + 1]; ++k) {
+        const int32_t* cv = cells + 3 * (int64_t)v2c[k];
+        tmp.push_back(cv[0]); tmp.push_back(cv[1]); tmp.push_back(cv[2]);
     }
-    std::vector<int32_t> v2c(3 * ne);
-    {
-        std::vector<int32_t> fill(v2c_ptr.begin(), v2c_ptr.end() - 1);
-        for (int64_t c = 0; c < ne; ++c)
-            for (int k = 0; k < 3; ++k) v2c[fill[cells[3 * c + k]]++] = (int32_t)c;
+    std::sort(tmp.begin(), tmp.end());
+    int n = (int)(std::unique(tmp.begin(), tmp.end()) - tmp.begin());
+    tmp.resize(n);
+    auto it = std::lower_bound(tmp.begin(), tmp.end(), v);
+    std::rotate(tmp.begin(), it, it + 1);  // move the diagonal to the front, rest stays ascending
+    return n;
+}
+
+static void build_v2c(int64_t nverts, int64_t ne, const int32_t* cells, std::vector<int32_t>& ptr,
+                      std::vector<int32_t>& lst) {
+    ptr.assign(nverts + 1, 0);
+    for (int64_t i = 0; i < 3 * ne; ++i) ptr[cells[i] + 1]++;
+    for (int64_t v = 0; v < nverts; ++v) ptr[v + 1] += ptr[v];
+    lst.resize(3 * ne);
+    std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
+    for (int64_t c = 0; c < ne; ++c)
+        for (int k = 0; k < 3; ++k) lst[fill[cells[3 * c + k]]++] = (int32_t)c;
+}
+
+std::string build_plan(int64_t n_own, int64_t n_loc, int64_t ne, const double* xy, const int32_t* cells_ext,
+                       const PlanOptions& opt, HostPlan& P) {
+    if (n_own <= 0 || ne <= 0 || n_loc < n_own) return "empty mesh";
+    if (n_loc > INT32_MAX / 2 || ne > INT32_MAX / 4) return "mesh too large for int32 indexing";
+    P.n_own = n_own;
+    P.n_loc = n_loc;
+    P.ne = ne;
+    for (int64_t c = 0; c < ne; ++c) {
+        const int32_t* cv = cells_ext + 3 * c;
+        for (int k = 0; k < 3; ++k)
+            if (cv[k] < 0 || cv[k] >= n_loc) return "cell references a vertex outside [0, nv)";
+        if (cv[0] == cv[1] || cv[1] == cv[2] || cv[0] == cv[2]) return "degenerate cell (repeated vertex)";
+        if (cv[0] >= n_own && cv[1] >= n_own && cv[2] >= n_own) return "cell touches no owned vertex";
     }
+
+    std::vector<int32_t> v2c_ptr, v2c, tmp;
+    tmp.reserve(64);
+    // ---- internal numbering of the owned vertices ----
+    P.perm.resize(n_loc);
+    std::iota(P.perm.begin(), P.perm.end(), 0);
+    if (opt.reorder) {
+        double x0 = xy[0], x1 = xy[0], y0 = xy[1], y1 = xy[1];
+        for (int64_t v = 0; v < n_own; ++v) {
+            x0 = std::min(x0, xy[2 * v]); x1 = std::max(x1, xy[2 * v]);
+            y0 = std::min(y0, xy[2 * v + 1]); y1 = std::max(y1, xy[2 * v + 1]);
+        }
+        const double ext = std::max(std::max(x1 - x0, y1 - y0), 1e-300);
+        const double scale = (double)((1u << 21) - 1) / ext;  // isotropic: cells of the Z-curve stay square
+        std::vector<std::pair<uint64_t, int32_t>> key(n_own);
+        for (int64_t v = 0; v < n_own; ++v) {
+            const uint64_t ix = (uint64_t)((xy[2 * v] - x0) * scale), iy = (uint64_t)((xy[2 * v + 1] - y0) * scale);
+            key[v] = {spread21(ix) | (spread21(iy) << 1), (int32_t)v};
+        }
+        std::sort(key.begin(), key.end());
+        // row lengths (in the caller's numbering), then sort each window by length, longest first
+        build_v2c(n_loc, ne, cells_ext, v2c_ptr, v2c);
+        std::vector<uint8_t> len(n_own);
+        for (int64_t v = 0; v < n_own; ++v) {
+            if (v2c_ptr[v + 1] == v2c_ptr[v]) return "mesh has a vertex that belongs to no cell";
+            int n = row_columns((int32_t)v, v2c_ptr.data(), v2c.data(), cells_ext, tmp);
+            if (n > 255) return "a vertex has more than 254 neighbours";
+            len[v] = (uint8_t)n;
+        }
+        const int64_t W = std::max(kSlice, opt.sort_window / kSlice * kSlice);
+        for (int64_t w0 = 0; w0 < n_own; w0 += W) {
+            const int64_t w1 = std::min(n_own, w0 + W);
+            std::stable_sort(key.begin() + w0, key.begin() + w1,
+                             [&](const std::pair<uint64_t, int32_t>& a, const std::pair<uint64_t, int32_t>& b) {
+                                 return len[a.second] > len[b.second];
+                             });
+        }
+        for (int64_t i = 0; i < n_own; ++i) P.perm[i] = key[i].second;
+    }
+    P.iperm.resize(n_loc);
+    for (int64_t i = 0; i < n_loc; ++i) P.iperm[P.perm[i]] = (int32_t)i;
+    P.xy.resize(2 * n_loc);
+    for (int64_t i = 0; i < n_loc; ++i) {
+        P.xy[2 * i] = xy[2 * (int64_t)P.perm[i]];
+        P.xy[2 * i + 1] = xy[2 * (int64_t)P.perm[i] + 1];
+    }
+    P.cells.resize(3 * ne);
+    for (int64_t i = 0; i < 3 * ne; ++i) P.cells[i] = P.iperm[cells_ext[i]];
+    const int32_t* cells = P.cells.data();
+
+    // ---- vertex -> incident cells (ascending cell id), internal numbering ----
+    build_v2c(n_loc, ne, cells, v2c_ptr, v2c);
+    for (int64_t v = 0; v < n_own; ++v)
+        if (v2c_ptr[v + 1] == v2c_ptr[v]) return "mesh has a vertex that belongs to no cell";
 
     // ---- "last cell wins": highest cell index containing v ----
-    P.lastcell.resize(nv);
-    for (int64_t v = 0; v < nv; ++v) P.lastcell[v] = v2c[v2c_ptr[v + 1] - 1];
+    P.lastcell.resize(n_own);
+    for (int64_t v = 0; v < n_own; ++v) P.lastcell[v] = v2c[v2c_ptr[v + 1] - 1];
 
-    // ---- CSR pattern: row v = sorted unique vertices of v's incident cells ----
-    P.rowptr.assign(nv + 1, 0);
-    std::vector<int32_t> tmp;
-    tmp.reserve(64);
-    // pass 1: counts
-    for (int64_t v = 0; v < nv; ++v) {
-        tmp.clear();
-        for (int32_t k = v2c_ptr[v]; k < v2c_ptr[v + 1]; ++k) {
-            const int32_t* cv = cells + 3 * (int64_t)v2c[k];
-            tmp.push_back(cv[0]); tmp.push_back(cv[1]); tmp.push_back(cv[2]);
-        }
-        std::sort(tmp.begin(), tmp.end());
-        int32_t n = (int32_t)(std::unique(tmp.begin(), tmp.end()) - tmp.begin());
-        P.rowptr[v + 1] = n;
-        P.max_row_len = std::max(P.max_row_len, (int)n);
+    // ---- SELL-64 pattern of the owned rows ----
+    SellPattern& A = P.A;
+    A.n_rows = (int32_t)n_own;
+    A.n_cols = (int32_t)n_loc;
+    A.nslice = (int32_t)((n_own + kSlice - 1) / kSlice);
+    A.rowlen.assign((size_t)A.nslice * kSlice, 0);
+    A.ptr.assign(A.nslice + 1, 0);
+    A.nnz = 0;
+    for (int64_t v = 0; v < n_own; ++v) {
+        int n = row_columns((int32_t)v, v2c_ptr.data(), v2c.data(), cells, tmp);
+        if (n > 255) return "a vertex has more than 254 neighbours";
+        A.rowlen[v] = (uint8_t)n;
+        A.max_row_len = std::max(A.max_row_len, n);
+        A.nnz += n;
     }
-    int64_t nnz = 0;
-    for (int64_t v = 0; v < nv; ++v) {
-        nnz += P.rowptr[v + 1];
-        if (nnz > INT32_MAX) return "nnz exceeds int32";
-        P.rowptr[v + 1] = (int32_t)nnz;
+    int64_t slots = 0;
+    for (int32_t s = 0; s < A.nslice; ++s) {
+        int w = 0;
+        for (int l = 0; l < kSlice; ++l) w = std::max(w, (int)A.rowlen[(size_t)s * kSlice + l]);
+        slots += (int64_t)w * kSlice;
+        if (slots > INT32_MAX) return "padded nnz exceeds int32";
+        A.ptr[s + 1] = (int32_t)slots;
     }
-    P.nnz = nnz;
-    P.colidx.resize(nnz);
-    P.diagpos.resize(nv);
-    for (int64_t v = 0; v < nv; ++v) {
-        tmp.clear();
-        for (int32_t k = v2c_ptr[v]; k < v2c_ptr[v + 1]; ++k) {
-            const int32_t* cv = cells + 3 * (int64_t)v2c[k];
-            tmp.push_back(cv[0]); tmp.push_back(cv[1]); tmp.push_back(cv[2]);
-        }
-        std::sort(tmp.begin(), tmp.end());
-        int32_t n = (int32_t)(std::unique(tmp.begin(), tmp.end()) - tmp.begin());
-        int32_t* dst = P.colidx.data() + P.rowptr[v];
-        for (int32_t i = 0; i < n; ++i) {
-            dst[i] = tmp[i];
-            if (tmp[i] == v) P.diagpos[v] = P.rowptr[v] + i;
+    A.slots = slots;
+    A.col.assign(slots, 0);
+    for (int32_t s = 0; s < A.nslice; ++s) {
+        const int32_t base = A.ptr[s];
+        const int w = (A.ptr[s + 1] - base) / kSlice;
+        for (int l = 0; l < kSlice; ++l) {
+            const int64_t v = (int64_t)s * kSlice + l;
+            int n = 0;
+            if (v < n_own) n = row_columns((int32_t)v, v2c_ptr.data(), v2c.data(), cells, tmp);
+            for (int k = 0; k < w; ++k)
+                A.col[base + k * kSlice + l] = (k < n) ? tmp[k] : (v < n_own ? (int32_t)v : 0);
         }
     }
 
-    // ---- assembly blocks: contiguous row ranges whose incident cells fit the LDS budget ----
-    P.rows_max = opt.rows_max;
+    // ---- assembly blocks: runs of slices whose incident cells fit the LDS budget ----
+    P.slices_max = std::max(1, opt.slices_max);
     P.cells_max = std::min(opt.cells_max, 16383);  // inccode keeps the cell slot in 14 bits
     std::vector<int32_t> mark(ne, -1), slot(ne, 0);
-    P.blk_row0.clear();
-    P.blk_cellptr.clear();
+    P.blk_slice0.assign(1, 0);
+    P.blk_cellptr.assign(1, 0);
     P.blk_cells.clear();
-    P.incptr.assign(nv + 1, 0);
-    P.inccode.resize(3 * ne);
-    P.blk_row0.push_back(0);
-    P.blk_cellptr.push_back(0);
-    int32_t blk = 0, rows_in = 0, cells_in = 0;
-    int64_t blk_first_row = 0;
-    auto close_block = [&](int64_t row_end) {
-        // cells of this block, ascending; assign slots; encode incidences of its rows
-        size_t c0 = P.blk_cells.size();
-        for (int64_t v = blk_first_row; v < row_end; ++v)
+    P.incptr.assign(v2c_ptr.begin(), v2c_ptr.begin() + n_own + 1);
+    P.inccode.assign(v2c_ptr[n_own], 0);
+    int32_t blk = 0, slices_in = 0, cells_in = 0, first_slice = 0;
+    auto close_block = [&](int32_t slice_end) {
+        const size_t c0 = P.blk_cells.size();
+        const int64_t ra = (int64_t)first_slice * kSlice, rb = std::min<int64_t>(n_own, (int64_t)slice_end * kSlice);
+        for (int64_t v = ra; v < rb; ++v)
             for (int32_t k = v2c_ptr[v]; k < v2c_ptr[v + 1]; ++k) {
-                int32_t c = v2c[k];
+                const int32_t c = v2c[k];
                 if (mark[c] == blk) { mark[c] = -2 - blk; P.blk_cells.push_back(c); }
             }
         std::sort(P.blk_cells.begin() + c0, P.blk_cells.end());
         for (size_t i = c0; i < P.blk_cells.size(); ++i) slot[P.blk_cells[i]] = (int32_t)(i - c0);
         int inc = 0;
-        for (int64_t v = blk_first_row; v < row_end; ++v) {
+        for (int64_t v = ra; v < rb; ++v)
             for (int32_t k = v2c_ptr[v]; k < v2c_ptr[v + 1]; ++k) {
-                int32_t c = v2c[k];
+                const int32_t c = v2c[k];
                 const int32_t* cv = cells + 3 * (int64_t)c;
-                int li = (cv[0] == v) ? 0 : (cv[1] == v) ? 1 : 2;
+                const int li = (cv[0] == v) ? 0 : (cv[1] == v) ? 1 : 2;
                 P.inccode[k] = (uint16_t)((slot[c] << 2) | li);
                 ++inc;
             }
-            P.incptr[v + 1] = v2c_ptr[v + 1];
-        }
         P.max_inc_per_block = std::max(P.max_inc_per_block, inc);
-        P.blk_row0.push_back((int32_t)row_end);
+        P.blk_slice0.push_back(slice_end);
         P.blk_cellptr.push_back((int32_t)P.blk_cells.size());
         ++blk;
-        rows_in = 0;
+        slices_in = 0;
         cells_in = 0;
-        blk_first_row = row_end;
+        first_slice = slice_end;
     };
-    for (int64_t v = 0; v < nv; ++v) {
-        int32_t fresh = 0;
-        for (int32_t k = v2c_ptr[v]; k < v2c_ptr[v + 1]; ++k)
-            if (mark[v2c[k]] != blk) ++fresh;
-        if (fresh > P.cells_max) return "a vertex has more incident cells than the assembly LDS budget";
-        if (rows_in > 0 && (rows_in >= P.rows_max || cells_in + fresh > P.cells_max)) close_block(v);
-        for (int32_t k = v2c_ptr[v]; k < v2c_ptr[v + 1]; ++k)
-            if (mark[v2c[k]] != blk) { mark[v2c[k]] = blk; ++cells_in; }
-        ++rows_in;
+    std::vector<int32_t> seen(ne, -1);
+    for (int32_t s = 0; s < A.nslice; ++s) {
+        const int64_t ra = (int64_t)s * kSlice, rb = std::min<int64_t>(n_own, ra + kSlice);
+        int fresh = 0;  // cells of this slice not yet staged by the open block
+        for (int64_t v = ra; v < rb; ++v)
+            for (int32_t k = v2c_ptr[v]; k < v2c_ptr[v + 1]; ++k) {
+                const int32_t c = v2c[k];
+                if (mark[c] != blk && seen[c] != s) { seen[c] = s; ++fresh; }
+            }
+        if (fresh > P.cells_max) return "one 64-row slice touches more cells than the assembly LDS budget";
+        if (slices_in > 0 && (slices_in >= P.slices_max || cells_in + fresh > P.cells_max)) close_block(s);
+        for (int64_t v = ra; v < rb; ++v)
+            for (int32_t k = v2c_ptr[v]; k < v2c_ptr[v + 1]; ++k) {
+                const int32_t c = v2c[k];
+                if (mark[c] != blk) { mark[c] = blk; ++cells_in; }
+            }
+        ++slices_in;
     }
-    close_block(nv);
-    // a cell may not be listed twice in one vertex's incidence (degenerate cell)
-    for (int64_t c = 0; c < ne; ++c) {
-        const int32_t* cv = cells + 3 * c;
-        if (cv[0] == cv[1] || cv[1] == cv[2] || cv[0] == cv[2]) return "degenerate cell (repeated vertex)";
-    }
+    close_block(A.nslice);
+    return std::string();
+}
 
-    // ---- SpMV row blocks (CSR-stream): contiguous rows with <= spmv_nnz stored entries ----
-    P.sp_row0.clear();
-    P.sp_row0.push_back(0);
-    int32_t r0 = 0;
-    if (P.max_row_len > opt.spmv_nnz) return "a row is longer than the SpMV LDS budget";
-    for (int64_t v = 0; v < nv; ++v) {
-        int32_t n_with = P.rowptr[v + 1] - P.rowptr[r0];
-        if ((v - r0) >= opt.spmv_rows || n_with > opt.spmv_nnz) {
-            P.sp_row0.push_back((int32_t)v);
-            r0 = (int32_t)v;
+void sell_to_csr(const HostPlan& P, const double* sell_vals, std::vector<int32_t>& rowptr,
+                 std::vector<int32_t>& colidx, std::vector<double>* vals) {
+    const SellPattern& A = P.A;
+    const int64_t n = P.n_own;
+    rowptr.assign(n + 1, 0);
+    for (int64_t e = 0; e < n; ++e) rowptr[e + 1] = rowptr[e] + A.rowlen[P.iperm[e]];
+    colidx.resize(A.nnz);
+    if (vals) vals->resize(A.nnz);
+    std::vector<std::pair<int32_t, double>> row;
+    for (int64_t e = 0; e < n; ++e) {
+        const int32_t i = P.iperm[e];
+        const int32_t s = i / kSlice, l = i % kSlice, base = A.ptr[s];
+        const int len = A.rowlen[i];
+        row.resize(len);
+        for (int k = 0; k < len; ++k) {
+            const int32_t slot = base + k * kSlice + l;
+            row[k] = {P.perm[A.col[slot]], sell_vals ? sell_vals[slot] : 0.0};
+        }
+        std::sort(row.begin(), row.end(), [](const std::pair<int32_t, double>& a, const std::pair<int32_t, double>& b) {
+            return a.first < b.first;
+        });
+        for (int k = 0; k < len; ++k) {
+            colidx[rowptr[e] + k] = row[k].first;
+            if (vals) (*vals)[rowptr[e] + k] = row[k].second;
         }
     }
-    P.sp_row0.push_back((int32_t)nv);
-    for (size_t b = 0; b + 1 < P.sp_row0.size(); ++b) {
-        P.sp_max_rows = std::max(P.sp_max_rows, P.sp_row0[b + 1] - P.sp_row0[b]);
-        P.sp_max_nnz = std::max(P.sp_max_nnz, P.rowptr[P.sp_row0[b + 1]] - P.rowptr[P.sp_row0[b]]);
-    }
-    return std::string();
 }
 
 }  // namespace shk

@@ -1,8 +1,14 @@
 // Host-side static plans built once per mesh (the mesh never changes during a run):
-//  - P1 CSR sparsity, what DOLFINx preallocates at /root/reference/source/solvers.py:51-52;
+//  - an internal vertex numbering (Morton order of the coordinates, then rows sorted by length
+//    inside 256-row windows) that makes every kernel's access pattern independent of the numbering
+//    the caller uses;
+//  - the P1 sparsity (what DOLFINx preallocates at /root/reference/source/solvers.py:51-52) stored as
+//    SELL-64: rows are grouped in slices of 64 (one wavefront), each slice padded to its longest row
+//    and stored column-major, diagonal first, so a wavefront streams values and column indices with
+//    fully coalesced loads and keeps its row sums in registers;
 //  - "last cell wins" table for the interpolations at solvers.py:186-192;
-//  - the atomic-free assembly plan (row-owning blocks + their cell lists + vertex->cell
-//    incidence in block-local numbering) and the CSR-stream SpMV row blocks.
+//  - the atomic-free assembly plan: blocks own whole slices, list every cell touching their rows,
+//    and know, per owned row, which staged cells contribute to it.
 #pragma once
 #include <cstdint>
 #include <string>
@@ -10,32 +16,50 @@
 
 namespace shk {
 
+constexpr int kSlice = 64;  // rows per SELL slice = wavefront width
+
 struct PlanOptions {
-    int rows_max = 256;    // rows owned by one assembly block
+    int slices_max = 4;    // slices (of 64 rows) owned by one assembly block
     int cells_max = 640;   // cells staged in LDS by one assembly block
-    int spmv_nnz = 2048;   // products staged in LDS by one SpMV row block
-    int spmv_rows = 512;   // row cap of one SpMV row block
+    int sort_window = 256; // rows per row-length sorting window (multiple of 64)
+    bool reorder = true;   // internal Morton + window sort (false: keep the caller's numbering)
 };
 
-struct HostPlan {
-    int64_t nv = 0, ne = 0, nnz = 0;
-    std::vector<int32_t> rowptr, colidx, diagpos;
-    std::vector<int32_t> lastcell;  // T*(v)
-    // assembly
-    int rows_max = 0, cells_max = 0;
-    std::vector<int32_t> blk_row0;     // nblk+1 : rows [blk_row0[b], blk_row0[b+1])
-    std::vector<int32_t> blk_cellptr;  // nblk+1 into blk_cells
-    std::vector<int32_t> blk_cells;    // global cell ids, ascending inside a block
-    std::vector<int32_t> incptr;       // nv+1 into inccode
-    std::vector<uint16_t> inccode;     // (block-local cell slot << 2) | local vertex index
-    int max_inc_per_block = 0;         // max over blocks of sum of incidences (LDS sizing)
-    // spmv
-    std::vector<int32_t> sp_row0;      // nsb+1
-    int sp_max_nnz = 0, sp_max_rows = 0;
+// SELL-64 sparsity of the owned rows; columns index owned + ghost vertices.
+struct SellPattern {
+    int32_t n_rows = 0, n_cols = 0, nslice = 0;
+    int64_t nnz = 0, slots = 0;
+    std::vector<int32_t> ptr;      // nslice+1 : first slot of each slice
+    std::vector<int32_t> col;      // slots   : column of slot ptr[s] + k*64 + lane (padding: the row itself / 0)
+    std::vector<uint8_t> rowlen;   // nslice*64 : stored entries of each row (0 for tail padding rows)
     int max_row_len = 0;
 };
 
-// Returns empty string on success, else an error message.
-std::string build_plan(int64_t nv, int64_t ne, const int32_t* cells, const PlanOptions& opt, HostPlan& out);
+struct HostPlan {
+    int64_t n_own = 0, n_loc = 0, ne = 0;
+    std::vector<int32_t> perm;     // internal -> external local vertex id (n_loc)
+    std::vector<int32_t> iperm;    // external -> internal
+    std::vector<double> xy;        // internal order, 2*n_loc
+    std::vector<int32_t> cells;    // 3*ne, internal vertex ids, caller's cell order
+    SellPattern A;
+    std::vector<int32_t> lastcell; // T*(v) for owned v
+    // assembly
+    int cells_max = 0, slices_max = 0;
+    std::vector<int32_t> blk_slice0;   // nblk+1 : slices [blk_slice0[b], blk_slice0[b+1])
+    std::vector<int32_t> blk_cellptr;  // nblk+1 into blk_cells
+    std::vector<int32_t> blk_cells;    // cell ids, ascending inside a block
+    std::vector<int32_t> incptr;       // n_own+1 into inccode
+    std::vector<uint16_t> inccode;     // (block-local cell slot << 2) | local vertex index
+    int max_inc_per_block = 0;
+};
+
+// xy: (n_loc,2) external order; cells: (ne,3) external local ids, every cell must touch at least one
+// owned vertex (id < n_own); ghosts are ids [n_own, n_loc).  Returns "" or an error message.
+std::string build_plan(int64_t n_own, int64_t n_loc, int64_t ne, const double* xy, const int32_t* cells,
+                       const PlanOptions& opt, HostPlan& out);
+
+// External CSR (rows = external owned ids, columns external local ids ascending) of a SELL pattern.
+void sell_to_csr(const HostPlan& P, const double* sell_vals, std::vector<int32_t>& rowptr,
+                 std::vector<int32_t>& colidx, std::vector<double>* vals);
 
 }  // namespace shk
