@@ -110,7 +110,8 @@ struct Ctx {
     double *d_F = nullptr, *d_vals = nullptr, *d_vals_s = nullptr, *d_dinv = nullptr;
     // Krylov vectors
     double *d_r = nullptr, *d_rhat = nullptr, *d_p = nullptr, *d_v = nullptr, *d_s = nullptr, *d_t = nullptr,
-           *d_y = nullptr;
+           *d_y = nullptr, *d_ytot = nullptr, *d_rhs = nullptr;
+    double cur_rtol2 = 0.0, cur_atol2 = 0.0;   // stopping rule of the inner solve being enqueued
     double* d_part = nullptr;  // 8 arrays of kMaxParts
     KrylovState* d_state = nullptr;
     KrylovState* h_state = nullptr;  // pinned, 2 slots
@@ -131,7 +132,7 @@ struct Ctx {
 };
 
 // partial-array slots
-enum { P_RR = 0, P_RHV = 1, P_TS = 2, P_TT = 3, P_RHT = 4, P_AUX = 5, P_COUNT = 8 };
+enum { P_RR = 0, P_RHV = 1, P_TS = 2, P_TT = 3, P_RHT = 4, P_AUX = 5, P_RHS = 6, P_COUNT = 8 };
 
 // launchers (shk_kernels.hip)
 hipError_t prepare_kernels(Ctx* c);
@@ -139,7 +140,9 @@ void launch_assemble(Ctx* c, double dt);
 void launch_scale(Ctx* c);
 void launch_spmv_plain(Ctx* c, const double* vals, const double* x, double* y);
 void launch_norm2(Ctx* c, const double* x, double* partials);
-void krylov_init(Ctx* c);
+void krylov_init(Ctx* c, const double* rhs);
+void launch_accumulate(Ctx* c, bool first);
+void launch_true_residual(Ctx* c);
 void krylov_iteration(Ctx* c, int it);
 void launch_newton_update(Ctx* c, bool apply);
 void launch_update_explicit(Ctx* c, double dt);

@@ -367,8 +367,8 @@ static SpmvArgs spmv_args(Ctx* c, const double* vals, const double* x, double* y
     a.A = c->sell();
     a.vals = vals; a.x = x; a.y = y; a.rhat = c->d_rhat; a.part = c->d_part; a.st = c->d_state;
     a.it = it; a.max_it = c->params.krylov_max_it; a.np = c->grid;
-    a.rtol2 = c->params.krylov_rtol * c->params.krylov_rtol;
-    a.atol2 = c->params.krylov_atol * c->params.krylov_atol;
+    a.rtol2 = c->cur_rtol2;
+    a.atol2 = c->cur_atol2;
     return a;
 }
 
@@ -395,10 +395,10 @@ void launch_norm2(Ctx* c, const double* x, double* partials) {
 // Merged-reduction BiCGStab (right preconditioning folded into A' = A D^-1), x0 = 0:
 //   init      r = rhat = p = rhs, y = 0, partial ||rhs||^2
 //   spmv<1>   [stop test on ||r||^2]  v = A' p, (rhat.v)
-//   k_bicg_s  alpha = rho / (rhat.v);  s = r - alpha v
+//   k_bicg_s  alpha = rho / (rhat.v);  s = r - alpha v, (rhat.s)
 //   spmv<2>   t = A' s, (t.s), (t.t), (rhat.t)
-//   k_bicg_u  omega = (t.s)/(t.t); rho' = -omega (rhat.t)   [(rhat.s) = 0 by construction]
-//             beta = (rho'/rho)(alpha/omega) = -alpha (rhat.t)/rho
+//   k_bicg_u  omega = (t.s)/(t.t); rho' = (rhat.r') = (rhat.s) - omega (rhat.t)
+//             beta = (rho'/rho)(alpha/omega)
 //             y += alpha p + omega s;  r = s - omega t;  p = r + beta (p - omega v);  partial ||r||^2
 // Two reduction points per iteration instead of three, four kernels instead of five.
 __global__ __launch_bounds__(kBlock) void k_bicg_init(int64_t n, const double* __restrict__ rhs,
@@ -423,9 +423,10 @@ __global__ __launch_bounds__(kBlock) void k_bicg_init(int64_t n, const double* _
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_bicg_s(int64_t n, int it, int np, const double* __restrict__ part,
+__global__ __launch_bounds__(kBlock) void k_bicg_s(int64_t n, int it, int np, double* __restrict__ part,
                                                    const double* __restrict__ r, const double* __restrict__ v,
-                                                   double* __restrict__ s, KrylovState* __restrict__ st) {
+                                                   const double* __restrict__ rhat, double* __restrict__ s,
+                                                   KrylovState* __restrict__ st) {
     __shared__ double sh4[4];
     if (st->done) return;
     const double rhv = reduce_partials(part + P_RHV * kMaxParts, np, sh4);
@@ -436,8 +437,14 @@ __global__ __launch_bounds__(kBlock) void k_bicg_s(int64_t n, int it, int np, co
         return;
     }
     if (lead) st->alpha = alpha;
-    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
-        s[i] = r[i] - alpha * v[i];
+    double a = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const double si = r[i] - alpha * v[i];
+        s[i] = si;
+        a += rhat[i] * si;
+    }
+    a = block_sum(a, sh4);
+    if (threadIdx.x == 0) part[P_RHS * kMaxParts + blockIdx.x] = a;
 }
 
 // Closes iteration `it` (it >= 0) and prepares p for iteration it+1.
@@ -448,19 +455,23 @@ __global__ __launch_bounds__(kBlock) void k_bicg_u(int64_t n, int it, int np, do
                                                    KrylovState* __restrict__ st) {
     __shared__ double sh4[4];
     if (st->done) return;
-    double ts = 0.0, tt = 0.0, rht = 0.0;
+    double ts = 0.0, tt = 0.0, rht = 0.0, rhs = 0.0;
     for (int i = threadIdx.x; i < np; i += kBlock) {
         ts += part[P_TS * kMaxParts + i];
         tt += part[P_TT * kMaxParts + i];
         rht += part[P_RHT * kMaxParts + i];
+        rhs += part[P_RHS * kMaxParts + i];
     }
     ts = block_sum(ts, sh4);
     tt = block_sum(tt, sh4);
     rht = block_sum(rht, sh4);
+    rhs = block_sum(rhs, sh4);
     const double alpha = st->alpha, rho = st->rho[it & 1];
     const double omega = (tt > 0.0) ? ts / tt : 0.0;
-    const double rho_new = -omega * rht;
-    const double beta = -alpha * rht / rho;
+    // (rhat, r_new) = (rhat, s) - omega (rhat, t); (rhat, s) vanishes only in exact arithmetic and is
+    // kept so that rho stays the inner product of the vectors actually stored
+    const double rho_new = rhs - omega * rht;
+    const double beta = (omega != 0.0) ? (rho_new / rho) * (alpha / omega) : 0.0;
     const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
     if (!isfinite(beta) || !isfinite(omega)) {
         if (lead) { st->breakdown = 1; st->converged = 0; st->its = it; st->done = 1; }
@@ -480,10 +491,42 @@ __global__ __launch_bounds__(kBlock) void k_bicg_u(int64_t n, int it, int np, do
     if (threadIdx.x == 0) part[P_RR * kMaxParts + blockIdx.x] = a;
 }
 
-void krylov_init(Ctx* c) {
+void krylov_init(Ctx* c, const double* rhs) {
     PhaseTimer t(c, SHK_PH_VECTOR);
-    hipLaunchKernelGGL(k_bicg_init, dim3(c->grid), dim3(kBlock), 0, c->stream, c->n_own, c->d_F, c->d_r, c->d_rhat,
+    hipLaunchKernelGGL(k_bicg_init, dim3(c->grid), dim3(kBlock), 0, c->stream, c->n_own, rhs, c->d_r, c->d_rhat,
                        c->d_p, c->d_y, c->d_part, c->d_state);
+}
+
+// Iterative refinement around BiCGStab (its recursive residual drifts from b - A x over thousands of
+// iterations): ytot (+)= y, then rt = F - A' ytot with ||rt||^2 partials.
+__global__ __launch_bounds__(kBlock) void k_accumulate(int64_t n, int first, const double* __restrict__ y,
+                                                       double* __restrict__ ytot) {
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        ytot[i] = first ? y[i] : ytot[i] + y[i];
+}
+__global__ __launch_bounds__(kBlock) void k_true_residual(int64_t n, const double* __restrict__ F,
+                                                          const double* __restrict__ Ay, double* __restrict__ rt,
+                                                          double* __restrict__ part) {
+    __shared__ double sh4[4];
+    double a = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const double r = F[i] - Ay[i];
+        rt[i] = r;
+        a += r * r;
+    }
+    a = block_sum(a, sh4);
+    if (threadIdx.x == 0) part[blockIdx.x] = a;
+}
+void launch_accumulate(Ctx* c, bool first) {
+    PhaseTimer t(c, SHK_PH_VECTOR);
+    hipLaunchKernelGGL(k_accumulate, dim3(c->grid), dim3(kBlock), 0, c->stream, c->n_own, first ? 1 : 0, c->d_y,
+                       c->d_ytot);
+}
+void launch_true_residual(Ctx* c) {  // d_rhs2 = F - A' ytot, partials in P_AUX
+    launch_spmv_plain(c, c->d_vals_s, c->d_ytot, c->d_t);
+    PhaseTimer t(c, SHK_PH_VECTOR);
+    hipLaunchKernelGGL(k_true_residual, dim3(c->grid), dim3(kBlock), 0, c->stream, c->n_own, c->d_F, c->d_t,
+                       c->d_rhs, c->d_part + P_AUX * kMaxParts);
 }
 
 void krylov_iteration(Ctx* c, int it) {
@@ -495,8 +538,8 @@ void krylov_iteration(Ctx* c, int it) {
     }
     {
         PhaseTimer t(c, SHK_PH_VECTOR);
-        hipLaunchKernelGGL(k_bicg_s, g, b, 0, c->stream, c->n_own, it, c->grid, part, c->d_r, c->d_v, c->d_s,
-                           c->d_state);
+        hipLaunchKernelGGL(k_bicg_s, g, b, 0, c->stream, c->n_own, it, c->grid, part, c->d_r, c->d_v, c->d_rhat,
+                           c->d_s, c->d_state);
     }
     {
         PhaseTimer t(c, SHK_PH_SPMV);
@@ -524,7 +567,7 @@ __global__ __launch_bounds__(kBlock) void k_newton_update(int64_t n, double rela
 void launch_newton_update(Ctx* c, bool apply) {
     PhaseTimer t(c, SHK_PH_OTHER);
     hipLaunchKernelGGL(k_newton_update, dim3(c->grid), dim3(kBlock), 0, c->stream, c->n_own, c->params.newton_relax,
-                       apply ? 1 : 0, c->d_y, c->d_dinv, c->f[SHK_DX], c->f[SHK_N]);
+                       apply ? 1 : 0, c->d_ytot, c->d_dinv, c->f[SHK_DX], c->f[SHK_N]);
 }
 
 // ------------------------------------------------------------------ explicit updates (R6-R8)

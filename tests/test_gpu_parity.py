@@ -68,7 +68,7 @@ def test_linear_solve(hip):
     J = sp.csr_matrix((va, ci, rp), shape=(dom.num_vertices,) * 2)
     F = ctx.residual()
     dx = ctx.get_field("dx")
-    assert np.linalg.norm(J @ dx - F) / np.linalg.norm(F) < 1e-9
+    assert np.linalg.norm(J @ dx - F) / np.linalg.norm(F) < 2e-10  # true residual, not the recursive one
     # the CPU twin of the same recurrence needs a similar number of iterations
     _, its_cpu, _ = O.jacobi_bicgstab(J, F, 1e-10, 1e-50, 20000)
     assert abs(its - its_cpu) <= max(5, 0.25 * its_cpu)
