@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="280x56", help="nx x ny of the CPU-baseline sample mesh (same geometry)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--transport", default="rccl", help="rccl (xGMI) | gloo (host-staged, tests)")
     return ap.parse_args()
 
 
@@ -142,8 +143,10 @@ def main():
             "parallelism": f"dd{world}" if world > 1 else "single",
         },
     }
-    if rank == 0 and not args.no_roofline:
-        out["roofline"] = run.roofline(HBM_PEAK_GBS)
+    if not args.no_roofline:
+        roof = run.roofline(HBM_PEAK_GBS)  # one more (collective) step with per-launch hipEvents
+        if rank == 0:
+            out["roofline"] = roof
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:

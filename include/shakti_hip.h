@@ -93,6 +93,26 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
                      const int32_t* cells, shk_ctx** out);
 int shk_destroy(shk_ctx* ctx);
 
+/* ---- domain decomposition (replaces the MPI layer under DOLFINx/PETSc) ----
+ * Halo plan of this subdomain: neighbour ranks (ascending); for neighbour k the owned local vertices
+ * send_idx[send_ptr[k] .. send_ptr[k+1]) are sent to it, and its values arrive in ghost vertices
+ * n_own + recv_ptr[k] .. n_own + recv_ptr[k+1] (ghosts are numbered by owner, in the owner's send order). */
+int shk_set_halo(shk_ctx* ctx, int32_t n_nbr, const int32_t* nbr_rank, const int64_t* send_ptr,
+                 const int32_t* send_idx, const int64_t* recv_ptr);
+/* RCCL transport over xGMI: rank 0 creates a 128-byte id, every rank joins with it (the id travels by
+ * whatever bootstrap the host has, e.g. torch.distributed broadcast). */
+int shk_comm_unique_id(void* id128);
+int shk_comm_init_rccl(shk_ctx* ctx, int32_t rank, int32_t nranks, const void* id128);
+/* Host-staged transport through caller callbacks (gloo / MPI / tests).  exchange(user, send, recv): `send`
+ * holds the packed values for all neighbours (send_ptr layout), fill `recv` (recv_ptr layout);
+ * allreduce(user, buf, n): in-place element-wise sum over ranks.  Both return 0 on success. */
+typedef int (*shk_exchange_fn)(void* user, const double* send, double* recv);
+typedef int (*shk_allreduce_fn)(void* user, double* buf, int64_t n);
+int shk_comm_init_callbacks(shk_ctx* ctx, int32_t rank, int32_t nranks, shk_exchange_fn exchange,
+                            shk_allreduce_fn allreduce, void* user);
+/* Refresh the ghost entries of a field from their owners (scatter_forward, solvers.py:197,229). */
+int shk_halo_update(shk_ctx* ctx, int32_t field);
+
 int shk_default_params(shk_params* p);
 int shk_set_params(shk_ctx* ctx, const shk_params* p);
 int shk_get_params(shk_ctx* ctx, shk_params* p);

@@ -46,8 +46,12 @@ EXPORTS = (
     "shk_get_params", "shk_set_quadrature", "shk_set_field", "shk_get_field", "shk_set_dirichlet",
     "shk_assemble", "shk_get_residual", "shk_csr_nnz", "shk_get_csr", "shk_linear_solve", "shk_spmv",
     "shk_newton_solve", "shk_update_explicit", "shk_step", "shk_sync", "shk_profile_enable",
-    "shk_profile_read", "shk_time_kernel", "shk_plan_stats",
+    "shk_profile_read", "shk_time_kernel", "shk_plan_stats", "shk_set_halo", "shk_comm_unique_id",
+    "shk_comm_init_rccl", "shk_comm_init_callbacks", "shk_halo_update",
 )
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64)
 
 _lib = None
 
@@ -91,6 +95,11 @@ def load():
         "shk_profile_read": ([vp, P(shk_profile), i32], C.c_int),
         "shk_time_kernel": ([vp, i32, i32, dbl, P(dbl)], C.c_int),
         "shk_plan_stats": ([vp, P(i64)], C.c_int),
+        "shk_set_halo": ([vp, i32, vp, vp, vp, vp], C.c_int),
+        "shk_comm_unique_id": ([vp], C.c_int),
+        "shk_comm_init_rccl": ([vp, i32, i32, vp], C.c_int),
+        "shk_comm_init_callbacks": ([vp, i32, i32, EXCHANGE_FN, ALLREDUCE_FN, vp], C.c_int),
+        "shk_halo_update": ([vp, i32], C.c_int),
     }
     for name, (args, res) in sig.items():
         fn = getattr(lib, name)
@@ -98,6 +107,14 @@ def load():
         fn.restype = res
     _lib = lib
     return lib
+
+
+def rccl_unique_id() -> bytes:
+    buf = C.create_string_buffer(128)
+    lib = load()
+    if lib.shk_comm_unique_id(C.cast(buf, C.c_void_p)) != 0:
+        raise ShaktiHipError(lib.shk_last_error().decode())
+    return buf.raw
 
 
 def _ptr(a: np.ndarray):
@@ -225,6 +242,51 @@ class ShaktiHip:
 
     def sync(self):
         self._check(self.lib.shk_sync(self._h))
+
+    # --- domain decomposition
+    def set_halo(self, nbr, send_ptr, send_idx, recv_ptr):
+        nbr = np.ascontiguousarray(nbr, dtype=np.int32)
+        sp = np.ascontiguousarray(send_ptr, dtype=np.int64)
+        si = np.ascontiguousarray(send_idx, dtype=np.int32)
+        rp = np.ascontiguousarray(recv_ptr, dtype=np.int64)
+        self._halo = (nbr, sp, si, rp)
+        self._check(self.lib.shk_set_halo(self._h, nbr.size, _ptr(nbr), _ptr(sp), _ptr(si), _ptr(rp)))
+
+    def comm_init_rccl(self, rank: int, nranks: int, unique_id: bytes):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._check(self.lib.shk_comm_init_rccl(self._h, rank, nranks, C.cast(buf, C.c_void_p)))
+
+    def comm_init_callbacks(self, rank: int, nranks: int, exchange, allreduce):
+        """exchange(send: np.ndarray, recv: np.ndarray) and allreduce(buf: np.ndarray) operate in place on
+        host views laid out by the halo plan; exceptions are reported as transport failures."""
+        nbr, sp, si, rp = self._halo
+        nsend, nrecv = int(sp[-1]), int(rp[-1])
+
+        def _ex(user, send_p, recv_p):
+            try:
+                send = np.ctypeslib.as_array(send_p, shape=(max(nsend, 1),))[:nsend]
+                recv = np.ctypeslib.as_array(recv_p, shape=(max(nrecv, 1),))[:nrecv]
+                exchange(send, recv)
+                return 0
+            except Exception:  # pragma: no cover - surfaced through the C error path
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def _ar(user, buf_p, n):
+            try:
+                allreduce(np.ctypeslib.as_array(buf_p, shape=(n,)))
+                return 0
+            except Exception:  # pragma: no cover
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._cb = (EXCHANGE_FN(_ex), ALLREDUCE_FN(_ar))  # keep the thunks alive
+        self._check(self.lib.shk_comm_init_callbacks(self._h, rank, nranks, self._cb[0], self._cb[1], None))
+
+    def halo_update(self, name: str):
+        self._check(self.lib.shk_halo_update(self._h, FIELDS[name]))
 
     # --- measurement
     def profile_enable(self, on: bool):

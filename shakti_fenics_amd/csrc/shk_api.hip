@@ -133,6 +133,7 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
     c->nblk = (int)P.blk_slice0.size() - 1;
     c->cells_staged = (int64_t)P.blk_cells.size();
     c->grid = (int)std::min<int64_t>(kMaxParts, std::max<int64_t>(1, (c->n_own + kBlock - 1) / kBlock));
+    c->np = c->grid;
     {
         const size_t E = P.cells_max, S = P.slices_max;
         size_t lds = 12 * E * sizeof(double) + 3 * E * sizeof(int) + (S + 1) * sizeof(int) +
@@ -184,6 +185,7 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
     if ((e = hipMemset(c->d_bcflag, 0, nl)) != hipSuccess) return bail(e, "memset");
     if ((e = dev_alloc(c, &c->d_part, (size_t)P_COUNT * kMaxParts)) != hipSuccess) return bail(e, "alloc partials");
     if ((e = hipMemset(c->d_part, 0, P_COUNT * kMaxParts * sizeof(double))) != hipSuccess) return bail(e, "memset");
+    c->d_red = c->d_part;
     if ((e = dev_alloc(c, &c->d_state, 1)) != hipSuccess) return bail(e, "alloc state");
     if ((e = hipMemset(c->d_state, 0, sizeof(KrylovState))) != hipSuccess) return bail(e, "memset");
     if ((e = hipHostMalloc((void**)&c->h_state, 2 * sizeof(KrylovState))) != hipSuccess) return bail(e, "pinned");
@@ -202,6 +204,10 @@ int shk_destroy(shk_ctx* ctx) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    comm_destroy(c);
+    if (c->comm.h_send) (void)hipHostFree(c->comm.h_send);
+    if (c->comm.h_recv) (void)hipHostFree(c->comm.h_recv);
+    if (c->comm.h_red) (void)hipHostFree(c->comm.h_red);
     for (auto& ev : c->ev_pool) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     for (hipEvent_t ev : c->poll_ev) if (ev) (void)hipEventDestroy(ev);
     for (void* p : c->allocs) (void)hipFree(p);
@@ -351,9 +357,11 @@ static int krylov_inner(Ctx* c, const double* rhs, int max_it, KrylovState* out)
     const int saved_max = c->params.krylov_max_it;
     c->params.krylov_max_it = max_it;
     auto enqueue = [&](int sl) -> hipError_t {
-        for (int k = 0; k < chunk; ++k) krylov_iteration(c, it + k);
+        hipError_t e = hipSuccess;
+        for (int k = 0; k < chunk; ++k)
+            if ((e = krylov_iteration(c, it + k)) != hipSuccess) return e;
         it += chunk;
-        hipError_t e = hipMemcpyAsync(&c->h_state[sl], c->d_state, sizeof(KrylovState), hipMemcpyDeviceToHost,
+        e = hipMemcpyAsync(&c->h_state[sl], c->d_state, sizeof(KrylovState), hipMemcpyDeviceToHost,
                                       c->stream);
         if (e != hipSuccess) return e;
         return hipEventRecord(c->poll_ev[sl], c->stream);
@@ -373,12 +381,12 @@ static int krylov_inner(Ctx* c, const double* rhs, int max_it, KrylovState* out)
     return rc;
 }
 
-static int read_aux_norm(Ctx* c, double* out) {
-    HIPCHK(hipMemcpyAsync(c->h_part, c->d_part + P_AUX * kMaxParts, (size_t)c->grid * sizeof(double),
+static int read_aux_norm(Ctx* c, double* out) {  // fixed-order host sum of the (reduced) P_AUX partials
+    HIPCHK(hipMemcpyAsync(c->h_part, c->d_red + P_AUX * kMaxParts, (size_t)c->np * sizeof(double),
                           hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     double s = 0.0;
-    for (int i = 0; i < c->grid; ++i) s += c->h_part[i];
+    for (int i = 0; i < c->np; ++i) s += c->h_part[i];
     *out = std::sqrt(s);
     return 0;
 }
@@ -387,6 +395,7 @@ static int read_aux_norm(Ctx* c, double* out) {
 // recursive residual is only trusted to stop an inner run; each run is followed by one explicit
 // residual, and the correction equation is solved again if the target was missed.
 static int krylov_solve(Ctx* c, int* its, int* converged, double* relres) {
+    HIPCHK(halo_exchange(c, c->d_dinv));  // ghost columns of A' = A D^-1 need their owners' diagonal
     launch_scale(c);
     const double rtol = c->params.krylov_rtol, atol = c->params.krylov_atol;
     int total = 0, conv = 0;
@@ -405,7 +414,7 @@ static int krylov_solve(Ctx* c, int* its, int* converged, double* relres) {
             target = std::max(rtol * rhs_norm, atol);
         }
         launch_accumulate(c, outer == 0);
-        launch_true_residual(c);
+        HIPCHK(launch_true_residual(c));
         if (read_aux_norm(c, &rt)) return -1;
         if (!(rt > target)) { conv = std::isfinite(rt) ? 1 : 0; break; }
         if (st.breakdown && st.its == 0) break;  // no progress possible
@@ -449,13 +458,8 @@ int shk_spmv(shk_ctx* ctx, const double* x_host, double* y_host) {
 // ||F||_2 with a fixed summation order (device partials, host sum of <= 1024 values).
 static int residual_norm(Ctx* c, double* out) {
     launch_norm2(c, c->d_F, c->d_part + P_AUX * kMaxParts);
-    HIPCHK(hipMemcpyAsync(c->h_part, c->d_part + P_AUX * kMaxParts, (size_t)c->grid * sizeof(double),
-                          hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    double s = 0.0;
-    for (int i = 0; i < c->grid; ++i) s += c->h_part[i];
-    *out = std::sqrt(s);
-    return 0;
+    HIPCHK(allreduce_parts(c, P_AUX, 1));
+    return read_aux_norm(c, out);
 }
 
 int shk_newton_solve(shk_ctx* ctx, double dt, shk_solve_info* info) {
@@ -465,6 +469,7 @@ int shk_newton_solve(shk_ctx* ctx, double dt, shk_solve_info* info) {
     HIPCHK(hipSetDevice(c->device));
     shk_solve_info I{};
     // DOLFINx NewtonSolver::solve: residual first, then J / solve / update / residual.
+    HIPCHK(halo_exchange(c, c->f[SHK_N]));  // form(x): ghost update of the iterate
     launch_assemble(c, dt);  // F and J of the current iterate in one pass
     c->assembled = true;
     c->assembled_dt = dt;
@@ -480,6 +485,7 @@ int shk_newton_solve(shk_ctx* ctx, double dt, shk_solve_info* info) {
         I.krylov_its += k;
         if (!kc) I.krylov_failed = 1;
         launch_newton_update(c, true);
+        HIPCHK(halo_exchange(c, c->f[SHK_N]));
         launch_assemble(c, dt);
         ++it;
         if (residual_norm(c, &r)) return -1;
@@ -499,7 +505,7 @@ int shk_update_explicit(shk_ctx* ctx, double dt) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!(dt > 0)) return fail("dt must be positive");
     HIPCHK(hipSetDevice(c->device));
-    launch_update_explicit(c, dt);
+    HIPCHK(launch_update_explicit(c, dt));
     HIPCHK(hipGetLastError());
     c->assembled = false;
     return 0;
@@ -511,6 +517,102 @@ int shk_step(shk_ctx* ctx, double dt, shk_solve_info* info) {
     if (info) *info = I;
     if (!I.converged) return 0;  // caller decides (the reference raises, solvers.py:179-183)
     return shk_update_explicit(ctx, dt);
+}
+
+int shk_set_halo(shk_ctx* ctx, int32_t n_nbr, const int32_t* nbr_rank, const int64_t* send_ptr,
+                 const int32_t* send_idx, const int64_t* recv_ptr) {
+    CHECK_CTX(ctx);
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (n_nbr < 0 || (n_nbr > 0 && (!nbr_rank || !send_ptr || !recv_ptr))) return fail("bad halo plan");
+    HIPCHK(hipSetDevice(c->device));
+    Comm& m = c->comm;
+    m.nbr.assign(nbr_rank, nbr_rank + n_nbr);
+    m.send_ptr.assign(1, 0);
+    m.recv_ptr.assign(1, 0);
+    if (n_nbr > 0) {
+        m.send_ptr.assign(send_ptr, send_ptr + n_nbr + 1);
+        m.recv_ptr.assign(recv_ptr, recv_ptr + n_nbr + 1);
+    }
+    for (int k = 0; k < n_nbr; ++k)
+        if (m.send_ptr[k + 1] < m.send_ptr[k] || m.recv_ptr[k + 1] < m.recv_ptr[k] || (k > 0 && m.nbr[k] <= m.nbr[k - 1]))
+            return fail("halo plan: offsets must be non-decreasing and neighbour ranks ascending");
+    const int64_t nsend = m.send_ptr.back(), nrecv = m.recv_ptr.back();
+    if (m.send_ptr[0] != 0 || m.recv_ptr[0] != 0) return fail("halo plan: offsets must start at 0");
+    if (nrecv != c->n_loc - c->n_own) return fail("halo plan: receive counts do not cover the ghost vertices");
+    if (nsend > 0 && !send_idx) return fail("halo plan: null send list");
+    std::vector<int32_t> idx((size_t)nsend);
+    for (int64_t i = 0; i < nsend; ++i) {
+        if (send_idx[i] < 0 || send_idx[i] >= c->n_own) return fail("halo plan: send index is not an owned vertex");
+        idx[i] = c->plan.iperm[send_idx[i]];
+    }
+    hipError_t e;
+    if ((e = dev_alloc(c, &m.d_send_idx, (size_t)nsend)) != hipSuccess) return fail("halo alloc");
+    if ((e = dev_alloc(c, &m.d_sendbuf, (size_t)nsend)) != hipSuccess) return fail("halo alloc");
+    if (nsend > 0) HIPCHK(hipMemcpy(m.d_send_idx, idx.data(), (size_t)nsend * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipHostMalloc((void**)&m.h_send, std::max<size_t>(1, (size_t)nsend) * sizeof(double)));
+    HIPCHK(hipHostMalloc((void**)&m.h_recv, std::max<size_t>(1, (size_t)nrecv) * sizeof(double)));
+    HIPCHK(hipHostMalloc((void**)&m.h_red, (size_t)P_COUNT * kMaxParts * sizeof(double)));
+    return 0;
+}
+
+static int comm_common(Ctx* c, int rank, int nranks) {
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail("bad rank / nranks");
+    for (int r : c->comm.nbr)
+        if (r < 0 || r >= nranks || r == rank) return fail("halo plan names a neighbour outside the communicator");
+    if (nranks > 1 && c->d_red == c->d_part) {
+        double* red = nullptr;
+        if (dev_alloc(c, &red, (size_t)P_COUNT * kMaxParts) != hipSuccess) return fail("alloc reduced partials");
+        HIPCHK(hipMemset(red, 0, (size_t)P_COUNT * kMaxParts * sizeof(double)));
+        c->d_red = red;
+        c->np = kMaxParts;  // every subdomain reduces the same zero-padded arrays
+    }
+    c->comm.rank = rank;
+    c->comm.nranks = nranks;
+    return 0;
+}
+
+int shk_comm_unique_id(void* id128) {
+    if (!id128) return fail("null id buffer");
+    if (const char* e = rccl_load()) return fail(e);
+    if (rccl_unique_id(id128)) return fail("ncclGetUniqueId failed");
+    return 0;
+}
+
+int shk_comm_init_rccl(shk_ctx* ctx, int32_t rank, int32_t nranks, const void* id128) {
+    CHECK_CTX(ctx);
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!id128) return fail("null id buffer");
+    if (c->comm.kind != Comm::NONE) return fail("communicator already initialised");
+    HIPCHK(hipSetDevice(c->device));
+    if (const char* e = rccl_load()) return fail(e);
+    if (comm_common(c, rank, nranks)) return -1;
+    if (const char* e = rccl_init(c, rank, nranks, id128)) return fail(std::string("ncclCommInitRank: ") + e);
+    return 0;
+}
+
+int shk_comm_init_callbacks(shk_ctx* ctx, int32_t rank, int32_t nranks, shk_exchange_fn exchange,
+                            shk_allreduce_fn allreduce, void* user) {
+    CHECK_CTX(ctx);
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!exchange || !allreduce) return fail("null callback");
+    if (c->comm.kind != Comm::NONE) return fail("communicator already initialised");
+    if (!c->comm.h_red) return fail("call shk_set_halo before initialising the communicator");
+    if (comm_common(c, rank, nranks)) return -1;
+    c->comm.cb_exchange = exchange;
+    c->comm.cb_allreduce = allreduce;
+    c->comm.cb_user = user;
+    c->comm.kind = Comm::CALLBACK;
+    return 0;
+}
+
+int shk_halo_update(shk_ctx* ctx, int32_t field) {
+    CHECK_CTX(ctx);
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (field < 0 || field >= SHK_FIELD_COUNT || field == SHK_Q) return fail("field id has no ghost segment");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(halo_exchange(c, c->f[field]));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
 }
 
 int shk_sync(shk_ctx* ctx) {

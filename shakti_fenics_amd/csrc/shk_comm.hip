@@ -1,0 +1,148 @@
+// Domain-decomposition communication: ghost (halo) exchange and reduction of the per-workgroup partial
+// sums across subdomains.  Replaces the MPI traffic DOLFINx/PETSc generate under
+// /root/reference/source/solvers.py:179,197,229 (ghost scatter_forward, VecNorm all-reduce) --
+// SURVEY.md section 2 "implicit collectives" and section 8(e).
+//
+// Transports (one per context):
+//   RCCL      grouped ncclSend/ncclRecv per neighbour + ncclAllReduce, all enqueued on the context's
+//             stream: no host synchronisation inside the Krylov loop.  librccl is dlopen()ed so that a
+//             single-GPU process never needs it and a torch process shares torch's copy.
+//   CALLBACK  host-staged: pack -> D2H -> user callback -> H2D.  Used by the gloo tests (several ranks on
+//             one GPU or none of RCCL's preconditions) and by any host MPI a user wants to plug in.
+// Receives land directly in the ghost segment of the vector: ghosts are numbered by owner rank, in
+// the owner's send order, so no unpack kernel is needed.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+
+#include "shk_device.h"
+
+namespace shk {
+
+struct RcclApi {
+    void* h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+static RcclApi g_rccl;
+
+const char* rccl_load() {
+    if (g_rccl.h) return nullptr;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return "cannot dlopen librccl.so.1";
+#define SYM(field, name)                                              \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, name)); \
+    if (!g_rccl.field) return "librccl lacks " name
+    SYM(GetUniqueId, "ncclGetUniqueId");
+    SYM(CommInitRank, "ncclCommInitRank");
+    SYM(CommDestroy, "ncclCommDestroy");
+    SYM(GroupStart, "ncclGroupStart");
+    SYM(GroupEnd, "ncclGroupEnd");
+    SYM(Send, "ncclSend");
+    SYM(Recv, "ncclRecv");
+    SYM(AllReduce, "ncclAllReduce");
+    SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    g_rccl.h = h;
+    return nullptr;
+}
+
+int rccl_unique_id(void* out128) {
+    ncclUniqueId id;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+    if (g_rccl.GetUniqueId(&id) != ncclSuccess) return -1;
+    std::memcpy(out128, &id, 128);
+    return 0;
+}
+
+const char* rccl_init(Ctx* c, int rank, int nranks, const void* id128) {
+    ncclUniqueId id;
+    std::memcpy(&id, id128, 128);
+    ncclComm_t comm = nullptr;
+    ncclResult_t r = g_rccl.CommInitRank(&comm, nranks, id, rank);
+    if (r != ncclSuccess) return g_rccl.GetErrorString(r);
+    c->comm.nccl = comm;
+    c->comm.kind = Comm::RCCL;
+    c->comm.rank = rank;
+    c->comm.nranks = nranks;
+    return nullptr;
+}
+
+void comm_destroy(Ctx* c) {
+    if (c->comm.kind == Comm::RCCL && c->comm.nccl && g_rccl.CommDestroy)
+        g_rccl.CommDestroy(reinterpret_cast<ncclComm_t>(c->comm.nccl));
+    c->comm.nccl = nullptr;
+    c->comm.kind = Comm::NONE;
+}
+
+__global__ __launch_bounds__(kBlock) void k_pack(int64_t n, const int32_t* __restrict__ idx,
+                                                 const double* __restrict__ v, double* __restrict__ buf) {
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        buf[i] = v[idx[i]];
+}
+
+// Fill the ghost segment [n_own, n_loc) of `vec` with the owners' current values.
+hipError_t halo_exchange(Ctx* c, double* vec) {
+    Comm& m = c->comm;
+    if (m.kind == Comm::NONE || m.nranks <= 1 || m.nbr.empty()) return hipSuccess;
+    PhaseTimer t(c, SHK_PH_HALO);
+    const int64_t nsend = m.send_ptr.back(), nrecv = m.recv_ptr.back();
+    if (nsend > 0) {
+        const int g = (int)std::min<int64_t>((nsend + kBlock - 1) / kBlock, 1024);
+        hipLaunchKernelGGL(k_pack, dim3(g), dim3(kBlock), 0, c->stream, nsend, m.d_send_idx, vec, m.d_sendbuf);
+    }
+    double* ghost = vec + c->n_own;
+    if (m.kind == Comm::RCCL) {
+        ncclComm_t comm = reinterpret_cast<ncclComm_t>(m.nccl);
+        g_rccl.GroupStart();
+        for (size_t k = 0; k < m.nbr.size(); ++k) {
+            const int64_t ns = m.send_ptr[k + 1] - m.send_ptr[k], nr = m.recv_ptr[k + 1] - m.recv_ptr[k];
+            if (ns > 0) g_rccl.Send(m.d_sendbuf + m.send_ptr[k], (size_t)ns, ncclDouble, m.nbr[k], comm, c->stream);
+            if (nr > 0) g_rccl.Recv(ghost + m.recv_ptr[k], (size_t)nr, ncclDouble, m.nbr[k], comm, c->stream);
+        }
+        ncclResult_t r = g_rccl.GroupEnd();
+        return r == ncclSuccess ? hipSuccess : hipErrorUnknown;
+    }
+    // CALLBACK: host-staged
+    hipError_t e = hipSuccess;
+    if (nsend > 0)
+        e = hipMemcpyAsync(m.h_send, m.d_sendbuf, (size_t)nsend * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return e;
+    if (m.cb_exchange(m.cb_user, m.h_send, m.h_recv) != 0) return hipErrorUnknown;
+    if (nrecv > 0)
+        e = hipMemcpyAsync(ghost, m.h_recv, (size_t)nrecv * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    return e;
+}
+
+// Element-wise sum over subdomains of `nslots` consecutive partial arrays starting at slot `first`.
+hipError_t allreduce_parts(Ctx* c, int first, int nslots) {
+    Comm& m = c->comm;
+    if (m.kind == Comm::NONE || m.nranks <= 1) return hipSuccess;
+    PhaseTimer t(c, SHK_PH_HALO);
+    // out of place: the local partials (d_part) keep zeros beyond this rank's grid, the sums go to d_red
+    const double* src = c->d_part + (size_t)first * kMaxParts;
+    double* dst = c->d_red + (size_t)first * kMaxParts;
+    const size_t n = (size_t)nslots * kMaxParts;
+    if (m.kind == Comm::RCCL) {
+        ncclResult_t r = g_rccl.AllReduce(src, dst, n, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(m.nccl), c->stream);
+        return r == ncclSuccess ? hipSuccess : hipErrorUnknown;
+    }
+    hipError_t e = hipMemcpyAsync(m.h_red, src, n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return e;
+    if (m.cb_allreduce(m.cb_user, m.h_red, (int64_t)n) != 0) return hipErrorUnknown;
+    return hipMemcpyAsync(dst, m.h_red, n * sizeof(double), hipMemcpyHostToDevice, c->stream);
+}
+
+}  // namespace shk

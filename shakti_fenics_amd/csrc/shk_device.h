@@ -79,8 +79,25 @@ struct AsmArgs {
     QuadArg quad;
 };
 
+// Communication state of a subdomain context (shk_comm.hip).
+struct Comm {
+    enum Kind { NONE = 0, RCCL = 1, CALLBACK = 2 } kind = NONE;
+    int rank = 0, nranks = 1;
+    void* nccl = nullptr;                    // ncclComm_t
+    shk_exchange_fn cb_exchange = nullptr;   // CALLBACK transport
+    shk_allreduce_fn cb_allreduce = nullptr;
+    void* cb_user = nullptr;
+    std::vector<int> nbr;                    // neighbour ranks, ascending
+    std::vector<int64_t> send_ptr, recv_ptr; // per-neighbour offsets into the packed buffers
+    int32_t* d_send_idx = nullptr;           // internal ids of the owned vertices to send
+    double* d_sendbuf = nullptr;
+    double *h_send = nullptr, *h_recv = nullptr, *h_red = nullptr;  // pinned staging (CALLBACK)
+};
+
 struct Ctx {
     int device = 0;
+    Comm comm;
+    int np = 0;     // partial-array length every kernel reduces: grid, or kMaxParts across subdomains
     hipStream_t stream = nullptr;
     int64_t n_own = 0, n_loc = 0, ne = 0, nnz = 0, slots = 0;
     shk_params params{};
@@ -112,7 +129,8 @@ struct Ctx {
     double *d_r = nullptr, *d_rhat = nullptr, *d_p = nullptr, *d_v = nullptr, *d_s = nullptr, *d_t = nullptr,
            *d_y = nullptr, *d_ytot = nullptr, *d_rhs = nullptr;
     double cur_rtol2 = 0.0, cur_atol2 = 0.0;   // stopping rule of the inner solve being enqueued
-    double* d_part = nullptr;  // 8 arrays of kMaxParts
+    double* d_part = nullptr;  // 8 arrays of kMaxParts: this subdomain's partial sums
+    double* d_red = nullptr;   // the same summed over subdomains (== d_part for a single context)
     KrylovState* d_state = nullptr;
     KrylovState* h_state = nullptr;  // pinned, 2 slots
     double* h_part = nullptr;        // pinned, kMaxParts
@@ -131,8 +149,8 @@ struct Ctx {
     }
 };
 
-// partial-array slots
-enum { P_RR = 0, P_RHV = 1, P_TS = 2, P_TT = 3, P_RHT = 4, P_AUX = 5, P_RHS = 6, P_COUNT = 8 };
+// partial-array slots; [RR, RHV] and [TS, TT, RHT, RHS] are the two per-iteration reduction groups
+enum { P_RR = 0, P_RHV = 1, P_TS = 2, P_TT = 3, P_RHT = 4, P_RHS = 5, P_AUX = 6, P_COUNT = 8 };
 
 // launchers (shk_kernels.hip)
 hipError_t prepare_kernels(Ctx* c);
@@ -142,14 +160,22 @@ void launch_spmv_plain(Ctx* c, const double* vals, const double* x, double* y);
 void launch_norm2(Ctx* c, const double* x, double* partials);
 void krylov_init(Ctx* c, const double* rhs);
 void launch_accumulate(Ctx* c, bool first);
-void launch_true_residual(Ctx* c);
-void krylov_iteration(Ctx* c, int it);
+hipError_t launch_true_residual(Ctx* c);
+hipError_t krylov_iteration(Ctx* c, int it);
 void launch_newton_update(Ctx* c, bool apply);
-void launch_update_explicit(Ctx* c, double dt);
+hipError_t launch_update_explicit(Ctx* c, double dt);
 void launch_permute_in(Ctx* c, const double* io, double* dst);            // dst[i] = io[perm[i]]
 void launch_permute_out(Ctx* c, const double* src, double* io);           // io[perm[i]] = src[i]
 void launch_split_q(Ctx* c, const double* io);                            // io interleaved, external order
 void launch_join_q(Ctx* c, double* io);
+
+// communication (shk_comm.hip)
+const char* rccl_load();
+int rccl_unique_id(void* out128);
+const char* rccl_init(Ctx* c, int rank, int nranks, const void* id128);
+void comm_destroy(Ctx* c);
+hipError_t halo_exchange(Ctx* c, double* vec);
+hipError_t allreduce_parts(Ctx* c, int first, int nslots);
 
 struct PhaseTimer {  // RAII hipEvent pair when profiling is on
     Ctx* c;

@@ -294,7 +294,7 @@ void launch_scale(Ctx* c) {
 // values / column indices is a contiguous 512 B / 256 B wave access and the row sum never leaves
 // its register.
 //   MODE 0: y = A x
-//   MODE 1: BiCGStab first product  v = A p, partial (rhat . v); its prologue is the convergence test
+//   MODE 1: BiCGStab first product  v = A p, partial (rhat . v)
 //   MODE 2: BiCGStab second product t = A s, partials (t . s), (t . t), (rhat . t)
 struct SpmvArgs {
     DevSell A;
@@ -304,8 +304,6 @@ struct SpmvArgs {
     const double* rhat;
     double* part;            // partial arrays (MODE 1, 2)
     KrylovState* st;
-    int it, max_it, np;
-    double rtol2, atol2;
 };
 
 template <int MODE>
@@ -314,20 +312,6 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const SpmvArgs a) {
     const int tid = threadIdx.x;
     if (MODE != 0) {
         if (a.st->done) return;
-    }
-    if (MODE == 1) {
-        // iteration `it` starts here: ||r||^2 of the previous update decides whether to go on
-        const double rr = reduce_partials(a.part + P_RR * kMaxParts, a.np, sh4);
-        const double target2 = (a.it == 0) ? fmax(a.rtol2 * rr, a.atol2) : a.st->target2;
-        const bool lead = (blockIdx.x == 0 && tid == 0);
-        int stop = 0, conv = 0;
-        if (!(rr > target2)) { stop = 1; conv = (rr <= target2); }  // also stops on NaN
-        else if (a.it >= a.max_it) stop = 1;
-        if (lead && a.it == 0) { a.st->target2 = target2; a.st->rhs2 = rr; a.st->rho[0] = rr; }
-        if (stop) {
-            if (lead) { a.st->converged = conv; a.st->its = a.it; a.st->rnorm2 = rr; a.st->done = 1; }
-            return;
-        }
     }
     const int lane = tid & 63, wave = tid >> 6;
     double d0 = 0.0, d1 = 0.0, d2 = 0.0;
@@ -362,19 +346,16 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const SpmvArgs a) {
     }
 }
 
-static SpmvArgs spmv_args(Ctx* c, const double* vals, const double* x, double* y, int it) {
+static SpmvArgs spmv_args(Ctx* c, const double* vals, const double* x, double* y) {
     SpmvArgs a;
     a.A = c->sell();
     a.vals = vals; a.x = x; a.y = y; a.rhat = c->d_rhat; a.part = c->d_part; a.st = c->d_state;
-    a.it = it; a.max_it = c->params.krylov_max_it; a.np = c->grid;
-    a.rtol2 = c->cur_rtol2;
-    a.atol2 = c->cur_atol2;
     return a;
 }
 
 void launch_spmv_plain(Ctx* c, const double* vals, const double* x, double* y) {
     PhaseTimer t(c, SHK_PH_SPMV);
-    hipLaunchKernelGGL(k_spmv<0>, dim3(c->grid), dim3(kBlock), 0, c->stream, spmv_args(c, vals, x, y, 0));
+    hipLaunchKernelGGL(k_spmv<0>, dim3(c->grid), dim3(kBlock), 0, c->stream, spmv_args(c, vals, x, y));
 }
 
 // ------------------------------------------------------------------ vector kernels
@@ -394,9 +375,9 @@ void launch_norm2(Ctx* c, const double* x, double* partials) {
 
 // Merged-reduction BiCGStab (right preconditioning folded into A' = A D^-1), x0 = 0:
 //   init      r = rhat = p = rhs, y = 0, partial ||rhs||^2
-//   spmv<1>   [stop test on ||r||^2]  v = A' p, (rhat.v)
-//   k_bicg_s  alpha = rho / (rhat.v);  s = r - alpha v, (rhat.s)
-//   spmv<2>   t = A' s, (t.s), (t.t), (rhat.t)
+//   spmv<1>   v = A' p, (rhat.v)                                         -- reduction point 1: ||r||^2, (rhat.v)
+//   k_bicg_s  [stop test on ||r||^2]  alpha = rho / (rhat.v);  s = r - alpha v, (rhat.s)
+//   spmv<2>   t = A' s, (t.s), (t.t), (rhat.t)                           -- reduction point 2
 //   k_bicg_u  omega = (t.s)/(t.t); rho' = (rhat.r') = (rhat.s) - omega (rhat.t)
 //             beta = (rho'/rho)(alpha/omega)
 //             y += alpha p + omega s;  r = s - omega t;  p = r + beta (p - omega v);  partial ||r||^2
@@ -423,17 +404,31 @@ __global__ __launch_bounds__(kBlock) void k_bicg_init(int64_t n, const double* _
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_bicg_s(int64_t n, int it, int np, double* __restrict__ part,
+__global__ __launch_bounds__(kBlock) void k_bicg_s(int64_t n, int it, int max_it, double rtol2, double atol2,
+                                                   int np, const double* red, double* part,
                                                    const double* __restrict__ r, const double* __restrict__ v,
                                                    const double* __restrict__ rhat, double* __restrict__ s,
                                                    KrylovState* __restrict__ st) {
     __shared__ double sh4[4];
     if (st->done) return;
-    const double rhv = reduce_partials(part + P_RHV * kMaxParts, np, sh4);
-    const double alpha = st->rho[it & 1] / rhv;
+    // ||r||^2 of the iterate that opened this iteration decides whether to go on (the test sits here,
+    // one kernel after the first product, so that it shares that product's reduction point)
+    const double rr = reduce_partials(red + P_RR * kMaxParts, np, sh4);
+    const double rhv = reduce_partials(red + P_RHV * kMaxParts, np, sh4);
+    const double target2 = (it == 0) ? fmax(rtol2 * rr, atol2) : st->target2;
     const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
+    if (lead && it == 0) { st->target2 = target2; st->rhs2 = rr; st->rho[0] = rr; }
+    int stop = 0, conv = 0;
+    if (!(rr > target2)) { stop = 1; conv = (rr <= target2); }  // also stops on NaN
+    else if (it >= max_it) stop = 1;
+    if (stop) {
+        if (lead) { st->converged = conv; st->its = it; st->rnorm2 = rr; st->done = 1; }
+        return;
+    }
+    const double rho = (it == 0) ? rr : st->rho[it & 1];  // rho_0 = (rhat, r_0) = ||rhs||^2
+    const double alpha = rho / rhv;
     if (!isfinite(alpha)) {
-        if (lead) { st->breakdown = 1; st->converged = 0; st->its = it; st->done = 1; }
+        if (lead) { st->breakdown = 1; st->converged = 0; st->its = it; st->rnorm2 = rr; st->done = 1; }
         return;
     }
     if (lead) st->alpha = alpha;
@@ -448,7 +443,7 @@ __global__ __launch_bounds__(kBlock) void k_bicg_s(int64_t n, int it, int np, do
 }
 
 // Closes iteration `it` (it >= 0) and prepares p for iteration it+1.
-__global__ __launch_bounds__(kBlock) void k_bicg_u(int64_t n, int it, int np, double* __restrict__ part,
+__global__ __launch_bounds__(kBlock) void k_bicg_u(int64_t n, int it, int np, const double* red, double* part,
                                                    const double* __restrict__ s, const double* __restrict__ t,
                                                    const double* __restrict__ v, double* __restrict__ p,
                                                    double* __restrict__ y, double* __restrict__ r,
@@ -457,10 +452,10 @@ __global__ __launch_bounds__(kBlock) void k_bicg_u(int64_t n, int it, int np, do
     if (st->done) return;
     double ts = 0.0, tt = 0.0, rht = 0.0, rhs = 0.0;
     for (int i = threadIdx.x; i < np; i += kBlock) {
-        ts += part[P_TS * kMaxParts + i];
-        tt += part[P_TT * kMaxParts + i];
-        rht += part[P_RHT * kMaxParts + i];
-        rhs += part[P_RHS * kMaxParts + i];
+        ts += red[P_TS * kMaxParts + i];
+        tt += red[P_TT * kMaxParts + i];
+        rht += red[P_RHT * kMaxParts + i];
+        rhs += red[P_RHS * kMaxParts + i];
     }
     ts = block_sum(ts, sh4);
     tt = block_sum(tt, sh4);
@@ -522,34 +517,43 @@ void launch_accumulate(Ctx* c, bool first) {
     hipLaunchKernelGGL(k_accumulate, dim3(c->grid), dim3(kBlock), 0, c->stream, c->n_own, first ? 1 : 0, c->d_y,
                        c->d_ytot);
 }
-void launch_true_residual(Ctx* c) {  // d_rhs2 = F - A' ytot, partials in P_AUX
+hipError_t launch_true_residual(Ctx* c) {  // d_rhs = F - A' ytot, partials in P_AUX
+    hipError_t e = halo_exchange(c, c->d_ytot);
+    if (e != hipSuccess) return e;
     launch_spmv_plain(c, c->d_vals_s, c->d_ytot, c->d_t);
     PhaseTimer t(c, SHK_PH_VECTOR);
     hipLaunchKernelGGL(k_true_residual, dim3(c->grid), dim3(kBlock), 0, c->stream, c->n_own, c->d_F, c->d_t,
                        c->d_rhs, c->d_part + P_AUX * kMaxParts);
+    return allreduce_parts(c, P_AUX, 1);
 }
 
-void krylov_iteration(Ctx* c, int it) {
+hipError_t krylov_iteration(Ctx* c, int it) {
     const dim3 g(c->grid), b(kBlock);
     double* part = c->d_part;
+    hipError_t e;
+    if ((e = halo_exchange(c, c->d_p)) != hipSuccess) return e;
     {
         PhaseTimer t(c, SHK_PH_SPMV);
-        hipLaunchKernelGGL(k_spmv<1>, g, b, 0, c->stream, spmv_args(c, c->d_vals_s, c->d_p, c->d_v, it));
+        hipLaunchKernelGGL(k_spmv<1>, g, b, 0, c->stream, spmv_args(c, c->d_vals_s, c->d_p, c->d_v));
     }
+    if ((e = allreduce_parts(c, P_RR, 2)) != hipSuccess) return e;
     {
         PhaseTimer t(c, SHK_PH_VECTOR);
-        hipLaunchKernelGGL(k_bicg_s, g, b, 0, c->stream, c->n_own, it, c->grid, part, c->d_r, c->d_v, c->d_rhat,
-                           c->d_s, c->d_state);
+        hipLaunchKernelGGL(k_bicg_s, g, b, 0, c->stream, c->n_own, it, c->params.krylov_max_it, c->cur_rtol2,
+                           c->cur_atol2, c->np, c->d_red, part, c->d_r, c->d_v, c->d_rhat, c->d_s, c->d_state);
     }
+    if ((e = halo_exchange(c, c->d_s)) != hipSuccess) return e;
     {
         PhaseTimer t(c, SHK_PH_SPMV);
-        hipLaunchKernelGGL(k_spmv<2>, g, b, 0, c->stream, spmv_args(c, c->d_vals_s, c->d_s, c->d_t, it));
+        hipLaunchKernelGGL(k_spmv<2>, g, b, 0, c->stream, spmv_args(c, c->d_vals_s, c->d_s, c->d_t));
     }
+    if ((e = allreduce_parts(c, P_TS, 4)) != hipSuccess) return e;
     {
         PhaseTimer t(c, SHK_PH_VECTOR);
-        hipLaunchKernelGGL(k_bicg_u, g, b, 0, c->stream, c->n_own, it, c->grid, part, c->d_s, c->d_t, c->d_v,
+        hipLaunchKernelGGL(k_bicg_u, g, b, 0, c->stream, c->n_own, it, c->np, c->d_red, part, c->d_s, c->d_t, c->d_v,
                            c->d_p, c->d_y, c->d_r, c->d_state);
     }
+    return hipSuccess;
 }
 
 // dx = D^-1 y (undo the right preconditioning); N <- N - relax dx   (NewtonSolver update)
@@ -645,7 +649,7 @@ __global__ __launch_bounds__(kBlock) void k_update_b(const UpdArgs a) {
     }
 }
 
-void launch_update_explicit(Ctx* c, double dt) {
+hipError_t launch_update_explicit(Ctx* c, double dt) {
     UpdArgs a;
     a.m.xy = c->d_xy; a.m.cells = c->d_cells;
     a.lastcell = c->d_lastcell;
@@ -659,12 +663,22 @@ void launch_update_explicit(Ctx* c, double dt) {
         PhaseTimer t(c, SHK_PH_UPDATE);
         hipLaunchKernelGGL(k_update_a, dim3(g), dim3(kBlock), 0, c->stream, a);
     }
+    hipError_t e = halo_exchange(c, c->d_melt_tmp);  // neighbours' new melt rate enters grad(melt_n) below
+    if (e != hipSuccess) return e;
     {
         PhaseTimer t(c, SHK_PH_UPDATE);
         hipLaunchKernelGGL(k_update_b, dim3(g), dim3(kBlock), 0, c->stream, a);
     }
     std::swap(c->f[SHK_MELT_N], c->d_melt_tmp);
     std::swap(c->f[SHK_B], c->d_b_tmp);
+    if (c->n_loc > c->n_own) {  // ghost copies of the updated state (scatter_forward, solvers.py:197,229)
+        if ((e = halo_exchange(c, c->f[SHK_B])) != hipSuccess) return e;
+        if ((e = halo_exchange(c, c->f[SHK_QX])) != hipSuccess) return e;
+        if ((e = halo_exchange(c, c->f[SHK_QY])) != hipSuccess) return e;
+        e = hipMemcpyAsync(c->f[SHK_N_N] + c->n_own, c->f[SHK_N] + c->n_own,
+                           (size_t)(c->n_loc - c->n_own) * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
+    }
+    return e;
 }
 
 // ------------------------------------------------------------------ field I/O in the caller's numbering
