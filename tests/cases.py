@@ -40,3 +40,16 @@ def rel_l2(a, b):
     b = np.asarray(b, dtype=np.float64).ravel()
     nb = np.linalg.norm(b)
     return np.linalg.norm(a - b) / (nb if nb > 0 else 1.0)
+
+
+def c1_case():
+    """Configuration C1: the cooke2-like plumbing case behind tests/golden/c1_5k_oracle.npz."""
+    from shakti_fenics_amd.synthetic import config_mesh
+    dom = config_mesh("c1_5k")
+    sf = synthetic_fields(dom, storage_on=True)
+    nv = dom.num_vertices
+    f = O.Fields(N=sf["N_init"].copy(), N_n=sf["N_init"].copy(), b=np.abs(sf["b_init"]), q=sf["q_init"].copy(),
+                 melt_n=np.zeros(nv), z_b=sf["z_b"], z_s=sf["z_s"], G=sf["G"], storage=sf["lake_bdry"],
+                 inputs=sf["inputs"])
+    bc = O.boundary_dofs(dom.xy, dom.cells, outflow_predicate(dom))
+    return dom, f, bc, N_BDRY

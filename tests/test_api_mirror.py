@@ -1,0 +1,74 @@
+"""The Python surface of the reference (model_setup / fem objects / setup contract) -- CPU part."""
+import numpy as np
+import pytest
+
+from shakti_fenics_amd.comm import SerialComm
+from shakti_fenics_amd.fem import Function, functionspace
+from shakti_fenics_amd.mesh import rectangle_mesh
+from shakti_fenics_amd.model_setup import model_setup, _points_in_polygon
+
+REFERENCE_ATTRS = ("comm rank size domain x y V V_flux mask OutflowBoundary bounds outflow_on storage_on z_b z_s G "
+                   "inputs b_init N_init q_init lake_bdry N_bdry b_min outline lake_name results_name setup_name "
+                   "timesteps nt_save nt_check").split()  # /root/reference/source/model_setup.py:21-66
+
+
+def test_model_setup_has_the_reference_attributes_and_defaults():
+    dom = rectangle_mesh(11, 9, 10e3, 8e3)
+    md = model_setup(SerialComm(), dom)
+    for a in REFERENCE_ATTRS:
+        assert hasattr(md, a), a
+    for m in ("set_lake_bdry", "interp_data", "get_buffer", "ghost_mask", "solve"):
+        assert callable(getattr(md, m))
+    assert md.outflow_on is True and md.storage_on is True and md.N_bdry == 0.0 and md.b_min == 1.0e-5
+    assert md.mask.all() and md.mask.size == dom.num_vertices
+    assert md.q_init.x.array.size == 2 * dom.num_vertices
+
+
+def test_function_semantics():
+    dom = rectangle_mesh(6, 5, 5.0, 4.0, jitter=0.0)
+    V, W = functionspace(dom, ("CG", 1)), functionspace(dom, ("P", 1, (2,)))
+    f = Function(V)
+    f.interpolate(lambda x: 2.0 * x[0] + x[1])               # x is (3, npts)
+    assert np.allclose(f.x.array, 2 * dom.xy[:, 0] + dom.xy[:, 1])
+    f.interpolate(lambda x: 7.0 + 0 * x[0])
+    assert (f.x.array == 7.0).all()
+    q = Function(W)
+    q.sub(0).interpolate(lambda x: x[0])
+    q.sub(1).interpolate(lambda x: -x[1])
+    assert np.allclose(q.x.array.reshape(-1, 2), np.column_stack((dom.xy[:, 0], -dom.xy[:, 1])))  # blocked layout
+    g = Function(V)
+    g.interpolate(f)
+    assert np.array_equal(g.x.array, f.x.array)
+    f.x.scatter_forward()
+
+
+def test_interp_data_is_bilinear_and_returns_the_interpolator():
+    dom = rectangle_mesh(21, 17, 10e3, 8e3)
+    md = model_setup(SerialComm(), dom)
+    xg, yg = np.linspace(-3e3, 13e3, 81), np.linspace(-3e3, 11e3, 71)
+    X, Y = np.meshgrid(xg, yg)
+    fi = md.interp_data("z_b", xg, yg, 3.0 + 2e-3 * X - 1e-3 * Y)   # f[y, x], linear => reproduced exactly
+    assert np.allclose(md.z_b.x.array, 3.0 + 2e-3 * md.x - 1e-3 * md.y, rtol=0, atol=1e-9)
+    assert abs(float(fi((1000.0, 2000.0))) - (3.0 + 2.0 - 2.0)) < 1e-9
+
+
+def test_point_in_polygon_and_lake_boundary():
+    dom = rectangle_mesh(21, 21, 10.0, 10.0, jitter=0.0)
+    md = model_setup(SerialComm(), dom)
+    sq = np.array([[2.2, 2.2], [7.7, 2.2], [7.7, 7.7], [2.2, 7.7]])
+    md.set_lake_bdry(sq)
+    want = (md.x > 2.2) & (md.x < 7.7) & (md.y > 2.2) & (md.y < 7.7)
+    assert np.array_equal(md.lake_bdry.x.array.astype(bool), want)
+    assert _points_in_polygon(np.array([0.0]), np.array([0.0]), sq)[0] == False  # noqa: E712
+
+
+def test_synthetic_setup_follows_the_setup_contract(tmp_path):
+    from shakti_fenics_amd.setups import setup_synthetic_cooke2 as S
+    md = S.initialize(SerialComm(), nx=21, ny=21, results_root=tmp_path)
+    assert md.N_bdry == 3.7e5 and md.setup_name == "setup_synthetic_cooke2"
+    assert callable(md.OutflowBoundary) and md.timesteps.size >= 2 and md.nt_save == 1
+    from shakti_fenics_amd.solvers import get_bcs
+    (dofs, val), = get_bcs(md)
+    assert val == 3.7e5 and dofs.size > 0
+    md.outflow_on = False
+    assert get_bcs(md) == []

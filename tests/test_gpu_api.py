@@ -1,0 +1,68 @@
+"""The reference's workflow end to end on the GPU: setup module -> md.solve() -> the 7 result files
+(`/root/reference/source/solvers.py:57-238`), and the pde_solver()/solver.solve(N) API (`:28-54,179`)."""
+import os
+
+import numpy as np
+import pytest
+
+import shakti_oracle as O
+from cases import rel_l2
+from shakti_fenics_amd.comm import SerialComm
+from shakti_fenics_amd.fem import Constant, Function
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_fields(md, storage_on=True):
+    nv = md.domain.num_vertices
+    return O.Fields(N=md.N_init.x.array.copy(), N_n=md.N_init.x.array.copy(), b=md.b_init.x.array.copy(),
+                    q=md.q_init.x.array.reshape(nv, 2).copy(), melt_n=np.zeros(nv), z_b=md.z_b.x.array,
+                    z_s=md.z_s.x.array, G=md.G.x.array,
+                    storage=md.lake_bdry.x.array if storage_on else np.zeros(nv), inputs=md.inputs.x.array)
+
+
+def test_md_solve_writes_the_reference_output_contract(tmp_path):
+    from shakti_fenics_amd.setups import setup_synthetic_cooke2 as S
+    from shakti_fenics_amd.solvers import get_bcs
+    md = S.initialize(SerialComm(), nx=41, ny=41, results_root=tmp_path)
+    nt = md.timesteps.size
+    md.solve()
+    res = md.results_name
+    for name in ("t", "nodes_x", "nodes_y", "b", "N", "qx", "qy"):
+        assert os.path.exists(f"{res}/{name}.npy"), name
+    nd = md.domain.num_vertices
+    nti = int(nt / md.nt_save)
+    assert np.load(f"{res}/t.npy").shape == (nti,)
+    assert np.array_equal(np.load(f"{res}/nodes_x.npy"), md.x) and np.array_equal(np.load(f"{res}/nodes_y.npy"), md.y)
+    N = np.load(f"{res}/N.npy")
+    assert N.shape == (nti, nd) and np.load(f"{res}/qx.npy").shape == (nti, nd)
+    assert os.path.exists(f"{res}/setup_synthetic_cooke2.py")      # copy of the setup file (solvers.py:125)
+    # same run through the oracle
+    (dofs, val), = get_bcs(md)
+    fo, log = O.run(md.domain.xy, md.domain.cells, _oracle_fields(md), md.timesteps, O.Params(), dofs, val, nsteps=nt)
+    assert rel_l2(N[-1], fo.N) < 1e-7
+    assert rel_l2(np.load(f"{res}/b.npy")[-1], fo.b) < 1e-7
+    assert list(np.load(f"{res}/newton_its.npy")) == [l["niter"] for l in log]
+    # an existing results directory is an error on every rank (solvers.py:91-102)
+    with pytest.raises(SystemExit):
+        md.solve()
+
+
+def test_pde_solver_object_api(tmp_path):
+    from shakti_fenics_amd.setups import setup_synthetic_cooke2 as S
+    from shakti_fenics_amd.solvers import get_bcs, pde_solver
+    md = S.initialize(SerialComm(), nx=31, ny=31, results_root=tmp_path)
+    N, b, N_n, melt_n = Function(md.V), Function(md.V), Function(md.V), Function(md.V)
+    q = Function(md.V_flux)
+    b.interpolate(md.b_init)
+    N_n.interpolate(md.N_init)
+    dt = Constant(md.domain, 360.0)
+    solver = pde_solver(md, N, N_n, b, q, melt_n, md.lake_bdry, dt)
+    assert np.array_equal(N.x.array, N_n.x.array)                  # initial guess (solvers.py:48)
+    niter, converged = solver.solve(N)
+    (dofs, val), = get_bcs(md)
+    fo = _oracle_fields(md)
+    n_o, conv_o, _ = O.newton_solve(md.domain.xy, md.domain.cells, fo, 360.0, O.Params(), dofs, val)
+    assert converged and conv_o and niter == n_o
+    assert rel_l2(N.x.array, fo.N) < 1e-8
+    solver.ctx.close()
