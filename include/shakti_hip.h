@@ -39,8 +39,12 @@ typedef struct shk_params {
     int32_t newton_max_it;
     int32_t krylov_max_it;
     int32_t krylov_check_every; /* iterations enqueued between host convergence polls */
-    int32_t reserved;
+    int32_t precond;            /* SHK_PC_JACOBI (north_star's solver, default) or SHK_PC_AMG */
 } shk_params;
+
+/* Right preconditioner of BiCGStab.  JACOBI is folded into the matrix (A D^-1).  AMG = one V(1,1) cycle of a
+ * static-pattern aggregation multigrid (single-subdomain contexts). */
+enum shk_precond { SHK_PC_JACOBI = 0, SHK_PC_AMG = 1 };
 
 enum shk_field {
     SHK_N = 0,       /* effective pressure, the Newton unknown          (solvers.py:129) */
@@ -71,7 +75,7 @@ typedef struct shk_solve_info {
 /* Device-side timings accumulated with hipEvents on the library's stream while profiling is on. */
 enum shk_phase {
     SHK_PH_ASSEMBLE = 0, SHK_PH_SPMV = 1, SHK_PH_VECTOR = 2, SHK_PH_UPDATE = 3, SHK_PH_OTHER = 4,
-    SHK_PH_HALO = 5, SHK_PH_COUNT = 6
+    SHK_PH_HALO = 5, SHK_PH_PRECOND = 6, SHK_PH_COUNT = 7
 };
 typedef struct shk_profile {
     double ms[SHK_PH_COUNT];      /* summed launch durations per phase */

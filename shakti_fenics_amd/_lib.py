@@ -23,7 +23,7 @@ class shk_params(C.Structure):
     _fields_ = [(n, C.c_double) for n in
                 ("g", "rho_i", "rho_w", "nu", "Lh", "omega", "n", "A", "b_min",
                  "newton_rtol", "newton_atol", "newton_relax", "krylov_rtol", "krylov_atol")] + \
-               [(n, C.c_int32) for n in ("newton_max_it", "krylov_max_it", "krylov_check_every", "reserved")]
+               [(n, C.c_int32) for n in ("newton_max_it", "krylov_max_it", "krylov_check_every", "precond")]
 
 
 class shk_solve_info(C.Structure):
@@ -31,7 +31,8 @@ class shk_solve_info(C.Structure):
                 ("krylov_failed", C.c_int32), ("residual0", C.c_double), ("residual", C.c_double)]
 
 
-PHASES = ("assemble", "spmv", "vector", "update", "other", "halo")
+PHASES = ("assemble", "spmv", "vector", "update", "other", "halo", "precond")
+PRECOND = dict(jacobi=0, amg=1)
 
 
 class shk_profile(C.Structure):

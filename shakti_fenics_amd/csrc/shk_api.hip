@@ -96,6 +96,7 @@ int shk_default_params(shk_params* p) {
     p->newton_rtol = 1e-9; p->newton_atol = 1e-10; p->newton_relax = 1.0; p->newton_max_it = 50;
     // the reference solves each Newton system exactly (LU); the Krylov loop is driven to 1e-10
     p->krylov_rtol = 1e-10; p->krylov_atol = 1e-50; p->krylov_max_it = 20000; p->krylov_check_every = 32;
+    p->precond = SHK_PC_JACOBI;
     return 0;
 }
 
@@ -125,6 +126,7 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
     if (const char* s = getenv("SHK_ASM_CELLS")) opt.cells_max = std::max(64, atoi(s));
     if (const char* s = getenv("SHK_SORT_WINDOW")) opt.sort_window = std::max(64, atoi(s));
     if (const char* s = getenv("SHK_REORDER")) opt.reorder = atoi(s) != 0;
+    if (const char* s = getenv("SHK_AMG")) opt.amg = atoi(s) != 0;
     std::string err = build_plan(c->n_own, c->n_loc, ne, xy, cells, opt, c->plan);
     if (!err.empty()) { delete c; return fail("plan: " + err); }
     const HostPlan& P = c->plan;
@@ -191,6 +193,49 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
     if ((e = hipHostMalloc((void**)&c->h_state, 2 * sizeof(KrylovState))) != hipSuccess) return bail(e, "pinned");
     if ((e = hipHostMalloc((void**)&c->h_part, kMaxParts * sizeof(double))) != hipSuccess) return bail(e, "pinned");
     if ((e = prepare_kernels(c)) != hipSuccess) return bail(e, "hipFuncSetAttribute(dynamic LDS)");
+    // multigrid hierarchy
+    if (!c->plan.amg.empty()) {
+        const size_t nx = c->plan.amg.size();
+        c->amg_xf.resize(nx);
+        c->amg_lv.resize(nx);  // [0] unused; [l] for 1 <= l < nx
+        for (size_t l = 0; l < nx; ++l) {
+            AmgLevelPlan& LP = c->plan.amg[l];
+            AmgXfer& X = c->amg_xf[l];
+            X.n_fine = LP.n_fine; X.n_coarse = LP.n_coarse; X.dense = LP.dense;
+            if ((e = upload(c, &X.agg, LP.agg)) != hipSuccess) return bail(e, "amg upload");
+            if ((e = upload(c, &X.members, LP.members)) != hipSuccess) return bail(e, "amg upload");
+            if ((e = upload(c, &X.gptr, LP.gptr)) != hipSuccess) return bail(e, "amg upload");
+            if ((e = upload(c, &X.glist, LP.glist)) != hipSuccess) return bail(e, "amg upload");
+            if (!LP.dense) {
+                AmgLevel& L = c->amg_lv[l + 1 < nx ? l + 1 : l];
+                if (l + 1 >= nx) return bail(hipErrorUnknown, "amg plan ends on a sparse level");
+                L.n = LP.Ac.n_rows; L.nslice = LP.Ac.nslice; L.slots = LP.Ac.slots;
+                if ((e = upload(c, &L.ptr, LP.Ac.ptr)) != hipSuccess) return bail(e, "amg upload");
+                if ((e = upload(c, &L.col, LP.Ac.col)) != hipSuccess) return bail(e, "amg upload");
+                if ((e = upload(c, &L.rowlen, LP.Ac.rowlen)) != hipSuccess) return bail(e, "amg upload");
+                if ((e = upload(c, &L.diag_slot, LP.diag_slot)) != hipSuccess) return bail(e, "amg upload");
+                const size_t nr = (size_t)L.nslice * kSlice;
+                if ((e = dev_alloc(c, &L.vals, (size_t)L.slots)) != hipSuccess) return bail(e, "amg alloc");
+                double** vs[] = {&L.dinv, &L.x, &L.x2, &L.r};
+                for (double** v : vs) {
+                    if ((e = dev_alloc(c, v, nr)) != hipSuccess) return bail(e, "amg alloc");
+                    if ((e = hipMemset(*v, 0, nr * sizeof(double))) != hipSuccess) return bail(e, "memset");
+                }
+            } else {
+                const size_t nc = (size_t)LP.n_coarse;
+                if ((e = dev_alloc(c, &c->d_cdense, nc * nc)) != hipSuccess) return bail(e, "amg alloc");
+                if ((e = dev_alloc(c, &c->d_cinv, nc * nc)) != hipSuccess) return bail(e, "amg alloc");
+                if ((e = dev_alloc(c, &c->d_cr, 64)) != hipSuccess) return bail(e, "amg alloc");
+                if ((e = dev_alloc(c, &c->d_cx, 64)) != hipSuccess) return bail(e, "amg alloc");
+            }
+            LP = AmgLevelPlan();  // host copy no longer needed
+        }
+        double** vs[] = {&c->d_amg_x0, &c->d_phat, &c->d_shat};
+        for (double** v : vs) {
+            if ((e = dev_alloc(c, v, nl)) != hipSuccess) return bail(e, "amg alloc");
+            if ((e = hipMemset(*v, 0, nl * sizeof(double))) != hipSuccess) return bail(e, "memset");
+        }
+    }
     *out = reinterpret_cast<shk_ctx*>(c);
     return 0;
 }
@@ -224,7 +269,11 @@ int shk_set_params(shk_ctx* ctx, const shk_params* p) {
     if (!(p->g > 0 && p->rho_i > 0 && p->rho_w > 0 && p->nu > 0 && p->Lh > 0)) return fail("non-positive constant");
     if (p->newton_max_it < 0 || p->krylov_max_it < 1 || p->krylov_check_every < 1) return fail("bad iteration limits");
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (p->precond != SHK_PC_JACOBI && p->precond != SHK_PC_AMG) return fail("unknown preconditioner id");
+    if (p->precond == SHK_PC_AMG && c->amg_xf.empty())
+        return fail("multigrid hierarchy unavailable for this context (subdomain context, tiny mesh, or SHK_AMG=0)");
     c->params = *p;
+    c->use_amg = p->precond == SHK_PC_AMG;
     derive_params(c);
     c->assembled = false;
     return 0;
@@ -395,8 +444,12 @@ static int read_aux_norm(Ctx* c, double* out) {  // fixed-order host sum of the 
 // recursive residual is only trusted to stop an inner run; each run is followed by one explicit
 // residual, and the correction equation is solved again if the target was missed.
 static int krylov_solve(Ctx* c, int* its, int* converged, double* relres) {
-    HIPCHK(halo_exchange(c, c->d_dinv));  // ghost columns of A' = A D^-1 need their owners' diagonal
-    launch_scale(c);
+    if (c->use_amg) {
+        amg_numeric_setup(c);   // Galerkin coarse operators of the Jacobian just assembled
+    } else {
+        HIPCHK(halo_exchange(c, c->d_dinv));  // ghost columns of A' = A D^-1 need their owners' diagonal
+        launch_scale(c);
+    }
     const double rtol = c->params.krylov_rtol, atol = c->params.krylov_atol;
     int total = 0, conv = 0;
     double target = 0.0, rhs_norm = 0.0, rt = 0.0;

@@ -79,6 +79,20 @@ struct AsmArgs {
     QuadArg quad;
 };
 
+// Multigrid hierarchy on the device (shk_amg.hip).  Level 0 is the Jacobian itself (Ctx::d_vals, d_dinv).
+struct AmgLevel {
+    int32_t n = 0, nslice = 0;
+    int64_t slots = 0;
+    int32_t *ptr = nullptr, *col = nullptr, *diag_slot = nullptr;
+    uint8_t* rowlen = nullptr;
+    double *vals = nullptr, *dinv = nullptr, *x = nullptr, *x2 = nullptr, *r = nullptr;
+};
+struct AmgXfer {  // level l -> l+1
+    int32_t n_fine = 0, n_coarse = 0;
+    int32_t *agg = nullptr, *members = nullptr, *gptr = nullptr, *glist = nullptr;
+    bool dense = false;
+};
+
 // Communication state of a subdomain context (shk_comm.hip).
 struct Comm {
     enum Kind { NONE = 0, RCCL = 1, CALLBACK = 2 } kind = NONE;
@@ -129,6 +143,12 @@ struct Ctx {
     double *d_r = nullptr, *d_rhat = nullptr, *d_p = nullptr, *d_v = nullptr, *d_s = nullptr, *d_t = nullptr,
            *d_y = nullptr, *d_ytot = nullptr, *d_rhs = nullptr;
     double cur_rtol2 = 0.0, cur_atol2 = 0.0;   // stopping rule of the inner solve being enqueued
+    // multigrid preconditioner (empty when unavailable: subdomain contexts, tiny meshes)
+    std::vector<AmgLevel> amg_lv;   // [0] unused, [l] = sparse coarse level l
+    std::vector<AmgXfer> amg_xf;    // [l] : level l -> l+1, the last one lands on the dense coarsest level
+    double *d_amg_x0 = nullptr, *d_phat = nullptr, *d_shat = nullptr;
+    double *d_cdense = nullptr, *d_cinv = nullptr, *d_cr = nullptr, *d_cx = nullptr;
+    bool use_amg = false;
     double* d_part = nullptr;  // 8 arrays of kMaxParts: this subdomain's partial sums
     double* d_red = nullptr;   // the same summed over subdomains (== d_part for a single context)
     KrylovState* d_state = nullptr;
@@ -175,6 +195,8 @@ int rccl_unique_id(void* out128);
 const char* rccl_init(Ctx* c, int rank, int nranks, const void* id128);
 void comm_destroy(Ctx* c);
 hipError_t halo_exchange(Ctx* c, double* vec);
+void amg_numeric_setup(Ctx* c);
+void amg_vcycle(Ctx* c, const double* rin, double* zout);
 hipError_t allreduce_parts(Ctx* c, int first, int nslots);
 
 struct PhaseTimer {  // RAII hipEvent pair when profiling is on

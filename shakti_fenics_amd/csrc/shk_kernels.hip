@@ -302,6 +302,7 @@ struct SpmvArgs {
     const double* x;
     double* y;
     const double* rhat;
+    const double* sdot;      // MODE 2: the vector s of (t . s) (== x unless a preconditioner sits in between)
     double* part;            // partial arrays (MODE 1, 2)
     KrylovState* st;
 };
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const SpmvArgs a) {
         if (row < a.A.n_rows) {
             a.y[row] = sum;
             if (MODE == 1) d0 += a.rhat[row] * sum;
-            if (MODE == 2) { d0 += sum * a.x[row]; d1 += sum * sum; d2 += a.rhat[row] * sum; }
+            if (MODE == 2) { d0 += sum * a.sdot[row]; d1 += sum * sum; d2 += a.rhat[row] * sum; }
         }
     }
     if (MODE == 1) {
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const SpmvArgs a) {
 static SpmvArgs spmv_args(Ctx* c, const double* vals, const double* x, double* y) {
     SpmvArgs a;
     a.A = c->sell();
-    a.vals = vals; a.x = x; a.y = y; a.rhat = c->d_rhat; a.part = c->d_part; a.st = c->d_state;
+    a.vals = vals; a.x = x; a.y = y; a.rhat = c->d_rhat; a.sdot = x; a.part = c->d_part; a.st = c->d_state;
     return a;
 }
 
@@ -445,9 +446,9 @@ __global__ __launch_bounds__(kBlock) void k_bicg_s(int64_t n, int it, int max_it
 // Closes iteration `it` (it >= 0) and prepares p for iteration it+1.
 __global__ __launch_bounds__(kBlock) void k_bicg_u(int64_t n, int it, int np, const double* red, double* part,
                                                    const double* __restrict__ s, const double* __restrict__ t,
-                                                   const double* __restrict__ v, double* __restrict__ p,
-                                                   double* __restrict__ y, double* __restrict__ r,
-                                                   KrylovState* __restrict__ st) {
+                                                   const double* __restrict__ v, double* p, const double* phat,
+                                                   const double* shat, double* __restrict__ y,
+                                                   double* __restrict__ r, KrylovState* __restrict__ st) {
     __shared__ double sh4[4];
     if (st->done) return;
     double ts = 0.0, tt = 0.0, rht = 0.0, rhs = 0.0;
@@ -476,7 +477,7 @@ __global__ __launch_bounds__(kBlock) void k_bicg_u(int64_t n, int it, int np, co
     double a = 0.0;
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         const double si = s[i], pi = p[i];
-        y[i] += alpha * pi + omega * si;
+        y[i] += alpha * phat[i] + omega * shat[i];  // phat = M^-1 p, shat = M^-1 s (aliases of p, s for Jacobi)
         const double ri = si - omega * t[i];
         r[i] = ri;
         p[i] = ri + beta * (pi - omega * v[i]);
@@ -520,7 +521,7 @@ void launch_accumulate(Ctx* c, bool first) {
 hipError_t launch_true_residual(Ctx* c) {  // d_rhs = F - A' ytot, partials in P_AUX
     hipError_t e = halo_exchange(c, c->d_ytot);
     if (e != hipSuccess) return e;
-    launch_spmv_plain(c, c->d_vals_s, c->d_ytot, c->d_t);
+    launch_spmv_plain(c, c->use_amg ? c->d_vals : c->d_vals_s, c->d_ytot, c->d_t);
     PhaseTimer t(c, SHK_PH_VECTOR);
     hipLaunchKernelGGL(k_true_residual, dim3(c->grid), dim3(kBlock), 0, c->stream, c->n_own, c->d_F, c->d_t,
                        c->d_rhs, c->d_part + P_AUX * kMaxParts);
@@ -531,10 +532,15 @@ hipError_t krylov_iteration(Ctx* c, int it) {
     const dim3 g(c->grid), b(kBlock);
     double* part = c->d_part;
     hipError_t e;
-    if ((e = halo_exchange(c, c->d_p)) != hipSuccess) return e;
+    // right preconditioner: Jacobi is folded into the matrix (A' = A D^-1, phat = p); multigrid is applied
+    const double* A = c->use_amg ? c->d_vals : c->d_vals_s;
+    double* phat = c->use_amg ? c->d_phat : c->d_p;
+    double* shat = c->use_amg ? c->d_shat : c->d_s;
+    if (c->use_amg) amg_vcycle(c, c->d_p, phat);
+    if ((e = halo_exchange(c, phat)) != hipSuccess) return e;
     {
         PhaseTimer t(c, SHK_PH_SPMV);
-        hipLaunchKernelGGL(k_spmv<1>, g, b, 0, c->stream, spmv_args(c, c->d_vals_s, c->d_p, c->d_v));
+        hipLaunchKernelGGL(k_spmv<1>, g, b, 0, c->stream, spmv_args(c, A, phat, c->d_v));
     }
     if ((e = allreduce_parts(c, P_RR, 2)) != hipSuccess) return e;
     {
@@ -542,27 +548,30 @@ hipError_t krylov_iteration(Ctx* c, int it) {
         hipLaunchKernelGGL(k_bicg_s, g, b, 0, c->stream, c->n_own, it, c->params.krylov_max_it, c->cur_rtol2,
                            c->cur_atol2, c->np, c->d_red, part, c->d_r, c->d_v, c->d_rhat, c->d_s, c->d_state);
     }
-    if ((e = halo_exchange(c, c->d_s)) != hipSuccess) return e;
+    if (c->use_amg) amg_vcycle(c, c->d_s, shat);
+    if ((e = halo_exchange(c, shat)) != hipSuccess) return e;
     {
         PhaseTimer t(c, SHK_PH_SPMV);
-        hipLaunchKernelGGL(k_spmv<2>, g, b, 0, c->stream, spmv_args(c, c->d_vals_s, c->d_s, c->d_t));
+        SpmvArgs a = spmv_args(c, A, shat, c->d_t);
+        a.sdot = c->d_s;
+        hipLaunchKernelGGL(k_spmv<2>, g, b, 0, c->stream, a);
     }
     if ((e = allreduce_parts(c, P_TS, 4)) != hipSuccess) return e;
     {
         PhaseTimer t(c, SHK_PH_VECTOR);
         hipLaunchKernelGGL(k_bicg_u, g, b, 0, c->stream, c->n_own, it, c->np, c->d_red, part, c->d_s, c->d_t, c->d_v,
-                           c->d_p, c->d_y, c->d_r, c->d_state);
+                           c->d_p, phat, shat, c->d_y, c->d_r, c->d_state);
     }
     return hipSuccess;
 }
 
 // dx = D^-1 y (undo the right preconditioning); N <- N - relax dx   (NewtonSolver update)
-__global__ __launch_bounds__(kBlock) void k_newton_update(int64_t n, double relax, int apply,
+__global__ __launch_bounds__(kBlock) void k_newton_update(int64_t n, double relax, int apply, int unscale,
                                                           const double* __restrict__ y,
                                                           const double* __restrict__ dinv, double* __restrict__ dx,
                                                           double* __restrict__ N) {
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        const double d = y[i] * dinv[i];
+        const double d = unscale ? y[i] * dinv[i] : y[i];
         dx[i] = d;
         if (apply) N[i] -= relax * d;
     }
@@ -571,7 +580,7 @@ __global__ __launch_bounds__(kBlock) void k_newton_update(int64_t n, double rela
 void launch_newton_update(Ctx* c, bool apply) {
     PhaseTimer t(c, SHK_PH_OTHER);
     hipLaunchKernelGGL(k_newton_update, dim3(c->grid), dim3(kBlock), 0, c->stream, c->n_own, c->params.newton_relax,
-                       apply ? 1 : 0, c->d_ytot, c->d_dinv, c->f[SHK_DX], c->f[SHK_N]);
+                       apply ? 1 : 0, c->use_amg ? 0 : 1, c->d_ytot, c->d_dinv, c->f[SHK_DX], c->f[SHK_N]);
 }
 
 // ------------------------------------------------------------------ explicit updates (R6-R8)

@@ -9,14 +9,43 @@
 
 namespace shk {
 
-static inline uint64_t spread21(uint64_t v) {  // bit k -> bit 2k for the low 21 bits... (32 handled)
-    v &= 0xFFFFFFFFull;
-    v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
-    v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
-    v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
-    v = (v | (v << 2)) & 0x3333333333333333ull;
-    v = (v | (v << 1)) & 0x5555555555555555ull;
-    return v;
+// k-d tree order: recursive splits along the longer side of the bounding box.  Split positions are
+// multiples of the largest power of 4 that keeps both parts non-empty, so every aligned run of 4, 16, 64,
+// ... consecutive vertices is a compact k-d cell: those runs are the multigrid aggregates of every level.
+struct KdPoint { double x, y; int32_t id; };
+
+static void kd_order(std::vector<KdPoint>& pts) {
+    struct Node { int64_t a, n; };
+    std::vector<Node> stack;
+    stack.push_back({0, (int64_t)pts.size()});
+    while (!stack.empty()) {
+        const Node nd = stack.back();
+        stack.pop_back();
+        if (nd.n <= 4) continue;
+        int64_t G = 1;
+        while (G * 4 <= nd.n / 2) G *= 4;
+        int64_t s = 0;
+        for (;;) {
+            s = ((2 * nd.a + nd.n + G) / (2 * G)) * G - nd.a;  // multiple of G nearest to the middle
+            if (s > 0 && s < nd.n) break;
+            G /= 4;
+            if (G < 1) { s = nd.n / 2; break; }
+        }
+        double x0 = pts[nd.a].x, x1 = x0, y0 = pts[nd.a].y, y1 = y0;
+        for (int64_t i = nd.a; i < nd.a + nd.n; ++i) {
+            x0 = std::min(x0, pts[i].x); x1 = std::max(x1, pts[i].x);
+            y0 = std::min(y0, pts[i].y); y1 = std::max(y1, pts[i].y);
+        }
+        auto b = pts.begin() + nd.a;
+        if (x1 - x0 >= y1 - y0)
+            std::nth_element(b, b + s, b + nd.n, [](const KdPoint& p, const KdPoint& q) {
+                return p.x < q.x || (p.x == q.x && p.id < q.id); });
+        else
+            std::nth_element(b, b + s, b + nd.n, [](const KdPoint& p, const KdPoint& q) {
+                return p.y < q.y || (p.y == q.y && p.id < q.id); });
+        stack.push_back({nd.a, s});
+        stack.push_back({nd.a + s, nd.n - s});
+    }
 }
 
 // sorted unique vertex set of the cells incident to v, diagonal first
@@ -67,19 +96,12 @@ std::string build_plan(int64_t n_own, int64_t n_loc, int64_t ne, const double* x
     P.perm.resize(n_loc);
     std::iota(P.perm.begin(), P.perm.end(), 0);
     if (opt.reorder) {
-        double x0 = xy[0], x1 = xy[0], y0 = xy[1], y1 = xy[1];
-        for (int64_t v = 0; v < n_own; ++v) {
-            x0 = std::min(x0, xy[2 * v]); x1 = std::max(x1, xy[2 * v]);
-            y0 = std::min(y0, xy[2 * v + 1]); y1 = std::max(y1, xy[2 * v + 1]);
-        }
-        const double ext = std::max(std::max(x1 - x0, y1 - y0), 1e-300);
-        const double scale = (double)((1u << 21) - 1) / ext;  // isotropic: cells of the Z-curve stay square
-        std::vector<std::pair<uint64_t, int32_t>> key(n_own);
-        for (int64_t v = 0; v < n_own; ++v) {
-            const uint64_t ix = (uint64_t)((xy[2 * v] - x0) * scale), iy = (uint64_t)((xy[2 * v + 1] - y0) * scale);
-            key[v] = {spread21(ix) | (spread21(iy) << 1), (int32_t)v};
-        }
-        std::sort(key.begin(), key.end());
+        std::vector<KdPoint> pts(n_own);
+        for (int64_t v = 0; v < n_own; ++v) pts[v] = {xy[2 * v], xy[2 * v + 1], (int32_t)v};
+        kd_order(pts);
+        std::vector<std::pair<int32_t, int32_t>> key(n_own);  // (k-d rank, external id)
+        for (int64_t i = 0; i < n_own; ++i) key[i] = {(int32_t)i, pts[i].id};
+        pts = std::vector<KdPoint>();
         // row lengths (in the caller's numbering), then sort each window by length, longest first
         build_v2c(n_loc, ne, cells_ext, v2c_ptr, v2c);
         std::vector<uint8_t> len(n_own);
@@ -93,11 +115,15 @@ std::string build_plan(int64_t n_own, int64_t n_loc, int64_t ne, const double* x
         for (int64_t w0 = 0; w0 < n_own; w0 += W) {
             const int64_t w1 = std::min(n_own, w0 + W);
             std::stable_sort(key.begin() + w0, key.begin() + w1,
-                             [&](const std::pair<uint64_t, int32_t>& a, const std::pair<uint64_t, int32_t>& b) {
+                             [&](const std::pair<int32_t, int32_t>& a, const std::pair<int32_t, int32_t>& b) {
                                  return len[a.second] > len[b.second];
                              });
         }
-        for (int64_t i = 0; i < n_own; ++i) P.perm[i] = key[i].second;
+        P.krank.resize(n_own);
+        for (int64_t i = 0; i < n_own; ++i) { P.perm[i] = key[i].second; P.krank[i] = key[i].first; }
+    } else {
+        P.krank.resize(n_own);
+        std::iota(P.krank.begin(), P.krank.end(), 0);
     }
     P.iperm.resize(n_loc);
     for (int64_t i = 0; i < n_loc; ++i) P.iperm[P.perm[i]] = (int32_t)i;
@@ -212,6 +238,146 @@ std::string build_plan(int64_t n_own, int64_t n_loc, int64_t ne, const double* x
         ++slices_in;
     }
     close_block(A.nslice);
+    if (opt.amg) {
+        std::string err = build_amg(P, opt);
+        if (!err.empty()) return err;
+    }
+    return std::string();
+}
+
+// ---- aggregation multigrid hierarchy (static patterns) ----
+static std::string coarsen(const SellPattern& Af, const std::vector<int32_t>& agg, int32_t n_coarse, bool dense,
+                           AmgLevelPlan& L) {
+    const int32_t nf = Af.n_rows;
+    L.n_fine = nf;
+    L.n_coarse = n_coarse;
+    L.agg = agg;
+    L.dense = dense;
+    L.members.assign((size_t)4 * n_coarse, -1);
+    {
+        std::vector<uint8_t> cnt(n_coarse, 0);
+        for (int32_t i = 0; i < nf; ++i) {
+            const int32_t I = agg[i];
+            if (cnt[I] >= 4) return "aggregate with more than 4 members";
+            L.members[(size_t)4 * I + cnt[I]++] = i;
+        }
+        for (int32_t I = 0; I < n_coarse; ++I) {
+            if (cnt[I] == 0) return "empty aggregate";
+            const int32_t g0 = L.members[(size_t)4 * I] / 256;
+            for (int m = 1; m < cnt[I]; ++m)
+                if (L.members[(size_t)4 * I + m] / 256 != g0) return "aggregate straddles a 256-row group";
+        }
+    }
+    // coarse rows: sorted unique aggregates of the members' columns, diagonal first
+    std::vector<int32_t> rp(n_coarse + 1, 0), ci;
+    std::vector<int32_t> tmp;
+    ci.reserve((size_t)Af.nnz / 2);
+    for (int32_t I = 0; I < n_coarse; ++I) {
+        tmp.clear();
+        for (int m = 0; m < 4; ++m) {
+            const int32_t i = L.members[(size_t)4 * I + m];
+            if (i < 0) continue;
+            const int32_t s = i / kSlice, l = i % kSlice, base = Af.ptr[s];
+            for (int k = 0; k < Af.rowlen[i]; ++k) tmp.push_back(agg[Af.col[base + k * kSlice + l]]);
+        }
+        std::sort(tmp.begin(), tmp.end());
+        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+        auto it = std::lower_bound(tmp.begin(), tmp.end(), I);
+        std::rotate(tmp.begin(), it, it + 1);
+        if (tmp.size() > 255) return "coarse row longer than 255";
+        ci.insert(ci.end(), tmp.begin(), tmp.end());
+        rp[I + 1] = (int32_t)ci.size();
+    }
+    std::vector<int32_t> target((size_t)Af.slots, -1);  // coarse slot of every fine slot
+    int64_t nslots_c;
+    if (dense) {
+        nslots_c = (int64_t)n_coarse * n_coarse;
+        for (int32_t i = 0; i < nf; ++i) {
+            const int32_t s = i / kSlice, l = i % kSlice, base = Af.ptr[s], I = agg[i];
+            for (int k = 0; k < Af.rowlen[i]; ++k) {
+                const int32_t slot = base + k * kSlice + l;
+                target[slot] = I * n_coarse + agg[Af.col[slot]];
+            }
+        }
+    } else {
+        SellPattern& C = L.Ac;
+        C.n_rows = n_coarse;
+        C.n_cols = n_coarse;
+        C.nslice = (n_coarse + kSlice - 1) / kSlice;
+        C.rowlen.assign((size_t)C.nslice * kSlice, 0);
+        C.ptr.assign(C.nslice + 1, 0);
+        C.nnz = rp[n_coarse];
+        for (int32_t I = 0; I < n_coarse; ++I) {
+            C.rowlen[I] = (uint8_t)(rp[I + 1] - rp[I]);
+            C.max_row_len = std::max(C.max_row_len, (int)C.rowlen[I]);
+        }
+        int64_t slots = 0;
+        for (int32_t s = 0; s < C.nslice; ++s) {
+            int w = 0;
+            for (int l = 0; l < kSlice; ++l) w = std::max(w, (int)C.rowlen[(size_t)s * kSlice + l]);
+            slots += (int64_t)w * kSlice;
+            C.ptr[s + 1] = (int32_t)slots;
+        }
+        C.slots = slots;
+        C.col.assign(slots, 0);
+        L.diag_slot.resize(n_coarse);
+        for (int32_t I = 0; I < n_coarse; ++I) {
+            const int32_t s = I / kSlice, l = I % kSlice, base = C.ptr[s];
+            const int w = (C.ptr[s + 1] - base) / kSlice;
+            for (int k = 0; k < w; ++k)
+                C.col[base + k * kSlice + l] = (k < C.rowlen[I]) ? ci[rp[I] + k] : I;
+            L.diag_slot[I] = base + l;
+        }
+        for (int32_t s = C.n_rows; s < C.nslice * kSlice; ++s) {  // tail padding rows point at column 0
+            const int32_t sl = s / kSlice, l = s % kSlice, base = C.ptr[sl];
+            const int w = (C.ptr[sl + 1] - base) / kSlice;
+            for (int k = 0; k < w; ++k) C.col[base + k * kSlice + l] = 0;
+        }
+        nslots_c = slots;
+        for (int32_t i = 0; i < nf; ++i) {
+            const int32_t s = i / kSlice, l = i % kSlice, base = Af.ptr[s], I = agg[i];
+            const int32_t cs = I / kSlice, cl = I % kSlice, cbase = C.ptr[cs];
+            const int32_t* row = ci.data() + rp[I];
+            const int len = rp[I + 1] - rp[I];
+            for (int k = 0; k < Af.rowlen[i]; ++k) {
+                const int32_t slot = base + k * kSlice + l;
+                const int32_t J = agg[Af.col[slot]];
+                int kk = 0;
+                while (kk < len && row[kk] != J) ++kk;
+                target[slot] = cbase + kk * kSlice + cl;
+            }
+        }
+    }
+    // invert: coarse slot -> ascending list of fine slots
+    L.gptr.assign(nslots_c + 1, 0);
+    for (int64_t s = 0; s < Af.slots; ++s)
+        if (target[s] >= 0) L.gptr[target[s] + 1]++;
+    for (int64_t s = 0; s < nslots_c; ++s) L.gptr[s + 1] += L.gptr[s];
+    L.glist.resize(L.gptr[nslots_c]);
+    std::vector<int32_t> fill(L.gptr.begin(), L.gptr.end() - 1);
+    for (int64_t s = 0; s < Af.slots; ++s)
+        if (target[s] >= 0) L.glist[fill[target[s]]++] = (int32_t)s;
+    return std::string();
+}
+
+std::string build_amg(HostPlan& P, const PlanOptions& opt) {
+    P.amg.clear();
+    P.amg.reserve(40);  // `Af` below points into this vector: no reallocation (4^40 rows is out of reach)
+    if (P.n_loc != P.n_own) return std::string();  // subdomain contexts keep Jacobi
+    const int coarsest = std::min(64, std::max(4, opt.amg_coarsest));
+    const SellPattern* Af = &P.A;
+    std::vector<int32_t> agg(P.n_own);
+    for (int64_t i = 0; i < P.n_own; ++i) agg[i] = P.krank[i] / 4;
+    while (Af->n_rows > coarsest) {
+        const int32_t nc = (Af->n_rows + 3) / 4;
+        P.amg.emplace_back();
+        std::string err = coarsen(*Af, agg, nc, nc <= coarsest, P.amg.back());
+        if (!err.empty()) { P.amg.clear(); return "amg: " + err; }
+        if (P.amg.back().dense) break;
+        Af = &P.amg.back().Ac;
+        agg.resize(nc);
+        for (int32_t I = 0; I < nc; ++I) agg[I] = I / 4;
+    }
     return std::string();
 }
 

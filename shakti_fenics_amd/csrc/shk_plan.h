@@ -1,7 +1,7 @@
 // Host-side static plans built once per mesh (the mesh never changes during a run):
-//  - an internal vertex numbering (Morton order of the coordinates, then rows sorted by length
-//    inside 256-row windows) that makes every kernel's access pattern independent of the numbering
-//    the caller uses;
+//  - an internal vertex numbering (k-d tree order of the coordinates whose leaves are runs of 4
+//    vertices, then rows sorted by length inside 256-row windows) that makes every kernel's access
+//    pattern independent of the numbering the caller uses and gives the multigrid its aggregates;
 //  - the P1 sparsity (what DOLFINx preallocates at /root/reference/source/solvers.py:51-52) stored as
 //    SELL-64: rows are grouped in slices of 64 (one wavefront), each slice padded to its longest row
 //    and stored column-major, diagonal first, so a wavefront streams values and column indices with
@@ -22,7 +22,9 @@ struct PlanOptions {
     int slices_max = 4;    // slices (of 64 rows) owned by one assembly block
     int cells_max = 640;   // cells staged in LDS by one assembly block
     int sort_window = 256; // rows per row-length sorting window (multiple of 64)
-    bool reorder = true;   // internal Morton + window sort (false: keep the caller's numbering)
+    bool reorder = true;   // internal k-d order + window sort (false: keep the caller's numbering)
+    bool amg = true;       // also build the aggregation-multigrid hierarchy (single-subdomain contexts only)
+    int amg_coarsest = 64; // rows of the dense coarsest level (<= 64)
 };
 
 // SELL-64 sparsity of the owned rows; columns index owned + ghost vertices.
@@ -35,8 +37,25 @@ struct SellPattern {
     int max_row_len = 0;
 };
 
+// One coarsening step of the static-pattern aggregation multigrid: 4 children per aggregate
+// (consecutive leaves of the k-d order), piecewise-constant prolongation, Galerkin coarse operator
+// A_c = P^T A P whose sparsity never changes, so its values are a fixed gather-sum of the finer values.
+struct AmgLevelPlan {
+    int32_t n_fine = 0, n_coarse = 0;
+    std::vector<int32_t> agg;       // n_fine          : aggregate (= coarse row) of each fine row
+    std::vector<int32_t> members;   // 4*n_coarse      : fine rows of each aggregate, -1 padded; all inside one
+                                    //                   256-row group of the fine level
+    SellPattern Ac;                 // coarse pattern (n_coarse rows), empty for the dense coarsest level
+    std::vector<int32_t> gptr;      // coarse slots+1 (or n_coarse^2+1 when dense) into glist
+    std::vector<int32_t> glist;     // fine slots summed into each coarse slot, ascending
+    std::vector<int32_t> diag_slot; // n_coarse        : slot of the coarse diagonal (sparse levels)
+    bool dense = false;
+};
+
 struct HostPlan {
     int64_t n_own = 0, n_loc = 0, ne = 0;
+    std::vector<int32_t> krank;        // k-d rank of each internal owned vertex (aggregate = krank / 4)
+    std::vector<AmgLevelPlan> amg;     // amg[l]: level l -> l+1
     std::vector<int32_t> perm;     // internal -> external local vertex id (n_loc)
     std::vector<int32_t> iperm;    // external -> internal
     std::vector<double> xy;        // internal order, 2*n_loc
@@ -57,6 +76,8 @@ struct HostPlan {
 // owned vertex (id < n_own); ghosts are ids [n_own, n_loc).  Returns "" or an error message.
 std::string build_plan(int64_t n_own, int64_t n_loc, int64_t ne, const double* xy, const int32_t* cells,
                        const PlanOptions& opt, HostPlan& out);
+
+std::string build_amg(HostPlan& P, const PlanOptions& opt);
 
 // External CSR (rows = external owned ids, columns external local ids ascending) of a SELL pattern.
 void sell_to_csr(const HostPlan& P, const double* sell_vals, std::vector<int32_t>& rowptr,

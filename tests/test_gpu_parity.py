@@ -57,9 +57,11 @@ def test_spmv_matches_scipy(hip):
     ctx.close()
 
 
-def test_linear_solve(hip):
-    dom, f, bc, g = make_case(perturb=True)
+@pytest.mark.parametrize("precond", ["jacobi", "amg"])
+def test_linear_solve(hip, precond):
+    dom, f, bc, g = make_case(nx=67, ny=45, perturb=True)
     ctx = hip.ShaktiHip(dom.xy, dom.cells)
+    ctx.set_params(precond=hip.PRECOND[precond])
     upload(ctx, f, bc, g)
     ctx.assemble(DT)
     its, conv, rr = ctx.linear_solve()
@@ -69,9 +71,12 @@ def test_linear_solve(hip):
     F = ctx.residual()
     dx = ctx.get_field("dx")
     assert np.linalg.norm(J @ dx - F) / np.linalg.norm(F) < 2e-10  # true residual, not the recursive one
-    # the CPU twin of the same recurrence needs a similar number of iterations
+    # the CPU twin of the Jacobi recurrence needs a similar number of iterations; multigrid far fewer
     _, its_cpu, _ = O.jacobi_bicgstab(J, F, 1e-10, 1e-50, 20000)
-    assert abs(its - its_cpu) <= max(5, 0.25 * its_cpu)
+    if precond == "jacobi":
+        assert abs(its - its_cpu) <= max(5, 0.3 * its_cpu)
+    else:
+        assert its < 0.5 * its_cpu
     ctx.close()
 
 
@@ -98,9 +103,11 @@ def test_newton_and_update_match_oracle(hip, raw_b):
     ctx.close()
 
 
-def test_ten_steps_match_oracle(hip):
+@pytest.mark.parametrize("precond", ["jacobi", "amg"])
+def test_ten_steps_match_oracle(hip, precond):
     dom, f, bc, g = make_case(nx=41, ny=31)
     ctx = hip.ShaktiHip(dom.xy, dom.cells)
+    ctx.set_params(precond=hip.PRECOND[precond])
     upload(ctx, f, bc, g)
     ts = np.arange(11) * DT
     fo, log = O.run(dom.xy, dom.cells, f.copy(), ts, O.Params(), bc, g, nsteps=10)

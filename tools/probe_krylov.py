@@ -7,9 +7,12 @@ import scipy.sparse as sp
 from shakti_fenics_amd.runner import SingleRunner
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c2_1m"
-cpu = len(sys.argv) > 2 and sys.argv[2] == "cpu"
+pc = sys.argv[2] if len(sys.argv) > 2 else "jacobi"
+cpu = False
+from shakti_fenics_amd import _lib
 r = SingleRunner(cfg)
 c = r.ctx
+c.set_params(precond=_lib.PRECOND[pc])
 for step in range(2):
     dt = 360.0 if step == 0 else 3600.0
     c.assemble(dt)
