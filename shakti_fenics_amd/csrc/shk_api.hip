@@ -271,7 +271,7 @@ int shk_set_params(shk_ctx* ctx, const shk_params* p) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (p->precond != SHK_PC_JACOBI && p->precond != SHK_PC_AMG) return fail("unknown preconditioner id");
     if (p->precond == SHK_PC_AMG && c->amg_xf.empty())
-        return fail("multigrid hierarchy unavailable for this context (subdomain context, tiny mesh, or SHK_AMG=0)");
+        return fail("multigrid hierarchy unavailable for this context (mesh of <= 64 vertices, or SHK_AMG=0)");
     c->params = *p;
     c->use_amg = p->precond == SHK_PC_AMG;
     derive_params(c);
@@ -445,6 +445,10 @@ static int read_aux_norm(Ctx* c, double* out) {  // fixed-order host sum of the 
 // residual, and the correction equation is solved again if the target was missed.
 static int krylov_solve(Ctx* c, int* its, int* converged, double* relres) {
     if (c->use_amg) {
+        // subdomain contexts precondition with the multigrid of their own diagonal block (additive Schwarz
+        // without overlap): ghost columns drop out of the smoother through a zero D^-1
+        if (c->n_loc > c->n_own)
+            HIPCHK(hipMemsetAsync(c->d_dinv + c->n_own, 0, (size_t)(c->n_loc - c->n_own) * sizeof(double), c->stream));
         amg_numeric_setup(c);   // Galerkin coarse operators of the Jacobian just assembled
     } else {
         HIPCHK(halo_exchange(c, c->d_dinv));  // ghost columns of A' = A D^-1 need their owners' diagonal

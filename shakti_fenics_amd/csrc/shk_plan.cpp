@@ -278,7 +278,10 @@ static std::string coarsen(const SellPattern& Af, const std::vector<int32_t>& ag
             const int32_t i = L.members[(size_t)4 * I + m];
             if (i < 0) continue;
             const int32_t s = i / kSlice, l = i % kSlice, base = Af.ptr[s];
-            for (int k = 0; k < Af.rowlen[i]; ++k) tmp.push_back(agg[Af.col[base + k * kSlice + l]]);
+            for (int k = 0; k < Af.rowlen[i]; ++k) {
+                const int32_t cj = Af.col[base + k * kSlice + l];
+                if (cj < nf) tmp.push_back(agg[cj]);  // ghost columns couple to other subdomains: left out
+            }
         }
         std::sort(tmp.begin(), tmp.end());
         tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
@@ -296,7 +299,7 @@ static std::string coarsen(const SellPattern& Af, const std::vector<int32_t>& ag
             const int32_t s = i / kSlice, l = i % kSlice, base = Af.ptr[s], I = agg[i];
             for (int k = 0; k < Af.rowlen[i]; ++k) {
                 const int32_t slot = base + k * kSlice + l;
-                target[slot] = I * n_coarse + agg[Af.col[slot]];
+                if (Af.col[slot] < nf) target[slot] = I * n_coarse + agg[Af.col[slot]];
             }
         }
     } else {
@@ -341,6 +344,7 @@ static std::string coarsen(const SellPattern& Af, const std::vector<int32_t>& ag
             const int len = rp[I + 1] - rp[I];
             for (int k = 0; k < Af.rowlen[i]; ++k) {
                 const int32_t slot = base + k * kSlice + l;
+                if (Af.col[slot] >= nf) continue;
                 const int32_t J = agg[Af.col[slot]];
                 int kk = 0;
                 while (kk < len && row[kk] != J) ++kk;
@@ -363,7 +367,6 @@ static std::string coarsen(const SellPattern& Af, const std::vector<int32_t>& ag
 std::string build_amg(HostPlan& P, const PlanOptions& opt) {
     P.amg.clear();
     P.amg.reserve(40);  // `Af` below points into this vector: no reallocation (4^40 rows is out of reach)
-    if (P.n_loc != P.n_own) return std::string();  // subdomain contexts keep Jacobi
     const int coarsest = std::min(64, std::max(4, opt.amg_coarsest));
     const SellPattern* Af = &P.A;
     std::vector<int32_t> agg(P.n_own);

@@ -23,7 +23,7 @@ struct PlanOptions {
     int cells_max = 640;   // cells staged in LDS by one assembly block
     int sort_window = 256; // rows per row-length sorting window (multiple of 64)
     bool reorder = true;   // internal k-d order + window sort (false: keep the caller's numbering)
-    bool amg = true;       // also build the aggregation-multigrid hierarchy (single-subdomain contexts only)
+    bool amg = true;       // also build the aggregation-multigrid hierarchy (of the owned diagonal block)
     int amg_coarsest = 64; // rows of the dense coarsest level (<= 64)
 };
 

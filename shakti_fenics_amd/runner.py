@@ -13,13 +13,13 @@ from .synthetic import CONFIGS, N_BDRY, outflow_predicate, synthetic_fields
 
 class SingleRunner:
     def __init__(self, config="c4_10m", order="morton", dt=3600.0, storage=False, moulins=0, device=0,
-                 krylov_rtol=1e-10, shape=None):
+                 krylov_rtol=1e-10, shape=None, precond="jacobi"):
         nx, ny, Lx, Ly = CONFIGS[config] if shape is None else shape
         self.dom = rectangle_mesh(nx, ny, Lx, Ly, order=order)
         self.dt = dt
         sf = synthetic_fields(self.dom, storage_on=storage, moulins=moulins)
         self.ctx = _lib.ShaktiHip(self.dom.xy, self.dom.cells, device=device)
-        self.ctx.set_params(krylov_rtol=krylov_rtol)
+        self.ctx.set_params(krylov_rtol=krylov_rtol, precond=_lib.PRECOND[precond])
         c = self.ctx
         c.set_field("z_b", sf["z_b"]); c.set_field("z_s", sf["z_s"]); c.set_field("G", sf["G"])
         c.set_field("inputs", sf["inputs"]); c.set_field("storage", sf["lake_bdry"])
@@ -40,6 +40,9 @@ class SingleRunner:
 
     def describe(self):
         return self._desc
+
+    def set_precond(self, name: str):
+        self.ctx.set_params(precond=_lib.PRECOND[name])
 
     def step(self, i=None):
         i = self.next_step if i is None else i
@@ -91,7 +94,7 @@ class PartitionedRunner(SingleRunner):
     the global synthetic mesh, keeps its subdomain and joins the communicator."""
 
     def __init__(self, rank, world, device, config="c4_10m", order="morton", dt=3600.0, storage=False,
-                 moulins=0, krylov_rtol=1e-10, shape=None, transport="rccl", group=None):
+                 moulins=0, krylov_rtol=1e-10, shape=None, transport="rccl", group=None, precond="jacobi"):
         from .distributed import make_context
         from .partition import partition
 
@@ -104,7 +107,7 @@ class PartitionedRunner(SingleRunner):
         self.nv_global, self.ne_global = dom.num_vertices, dom.num_cells
         g = sub.gid
         self.ctx = c = make_context(sub, device, transport, group)
-        c.set_params(krylov_rtol=krylov_rtol)
+        c.set_params(krylov_rtol=krylov_rtol, precond=_lib.PRECOND[precond])
         c.set_field("z_b", sf["z_b"][g]); c.set_field("z_s", sf["z_s"][g]); c.set_field("G", sf["G"][g])
         c.set_field("inputs", sf["inputs"][g]); c.set_field("storage", sf["lake_bdry"][g])
         c.set_field("b", np.abs(sf["b_init"][g]))
@@ -146,6 +149,7 @@ class PartitionedRunner(SingleRunner):
 def make_runner(args, rank: int, world: int, local_rank: int):
     if world == 1:
         return SingleRunner(args.config, args.order, args.dt, bool(args.storage), args.moulins, local_rank,
-                            args.krylov_rtol)
+                            args.krylov_rtol, precond=getattr(args, "precond", "jacobi"))
     return PartitionedRunner(rank, world, local_rank, args.config, args.order, args.dt, bool(args.storage),
-                             args.moulins, args.krylov_rtol, transport=getattr(args, "transport", "rccl"))
+                             args.moulins, args.krylov_rtol, transport=getattr(args, "transport", "rccl"),
+                             precond=getattr(args, "precond", "jacobi"))

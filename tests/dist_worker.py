@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--ny", type=int, default=31)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--out", default="")
+    ap.add_argument("--precond", default="jacobi")
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -38,7 +39,7 @@ def main():
     from shakti_fenics_amd.runner import PartitionedRunner, SingleRunner
 
     shape = (a.nx, a.ny, 20e3, 10e3)
-    run = PartitionedRunner(rank, world, dev, shape=shape, storage=True, transport=a.transport)
+    run = PartitionedRunner(rank, world, dev, shape=shape, storage=True, transport=a.transport, precond=a.precond)
     infos = []
     for i in range(a.steps):
         info = run.step(i)
@@ -52,7 +53,7 @@ def main():
     ok = True
     report = {"world": world, "transport": a.transport, "infos": infos}
     if rank == 0:
-        ref = SingleRunner(shape=shape, storage=True, device=dev)
+        ref = SingleRunner(shape=shape, storage=True, device=dev, precond=a.precond)
         ref_infos = []
         for i in range(a.steps):
             info = ref.step(i)

@@ -12,7 +12,7 @@ cpu = False
 from shakti_fenics_amd import _lib
 r = SingleRunner(cfg)
 c = r.ctx
-c.set_params(precond=_lib.PRECOND[pc])
+c.set_params(precond=_lib.PRECOND[pc], krylov_max_it=int(sys.argv[3]) if len(sys.argv) > 3 else 20000)
 for step in range(2):
     dt = 360.0 if step == 0 else 3600.0
     c.assemble(dt)
