@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--cpu-sample", default="280x56", help="nx x ny of the CPU-baseline sample mesh (same geometry)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--transport", default="rccl", help="rccl (xGMI) | gloo (host-staged, tests)")
-    ap.add_argument("--precond", default="jacobi", help="jacobi (north_star's solver; the headline) | amg")
+    ap.add_argument("--precond", default="amg", help="amg (aggregation multigrid, default) | jacobi (north_star's solver; diverges at 10M DOF)")
     ap.add_argument("--amg-steps", type=int, default=2, help="extra steps timed with the multigrid preconditioner (N=1)")
     ap.add_argument("--quiet", action="store_true")
     return ap.parse_args()
@@ -92,8 +92,13 @@ def main():
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.transport == "gloo":   # rehearsal: several ranks on whatever GPUs exist, host-staged halo
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
 
@@ -129,7 +134,7 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall], dtype=torch.float64, device="cpu" if args.transport == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
 
