@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--moulins", type=int, default=0)
     ap.add_argument("--krylov-rtol", type=float, default=1e-10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", default="280x56", help="nx x ny of the CPU-baseline sample mesh (same geometry)")
+    ap.add_argument("--cpu-sample", default="560x112", help="nx x ny of the CPU-baseline sample mesh (same geometry)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--transport", default="rccl", help="rccl (xGMI) | gloo (host-staged, tests)")
     ap.add_argument("--precond", default="amg", help="amg (aggregation multigrid, default) | jacobi (north_star's solver; diverges at 10M DOF)")

@@ -43,7 +43,7 @@ typedef struct shk_params {
 } shk_params;
 
 /* Right preconditioner of BiCGStab.  JACOBI is folded into the matrix (A D^-1).  AMG = one V(1,1) cycle of a
- * static-pattern aggregation multigrid (single-subdomain contexts). */
+ * static-pattern aggregation multigrid (of the owned diagonal block on subdomain contexts). */
 enum shk_precond { SHK_PC_JACOBI = 0, SHK_PC_AMG = 1 };
 
 enum shk_field {
@@ -75,7 +75,8 @@ typedef struct shk_solve_info {
 /* Device-side timings accumulated with hipEvents on the library's stream while profiling is on. */
 enum shk_phase {
     SHK_PH_ASSEMBLE = 0, SHK_PH_SPMV = 1, SHK_PH_VECTOR = 2, SHK_PH_UPDATE = 3, SHK_PH_OTHER = 4,
-    SHK_PH_HALO = 5, SHK_PH_PRECOND = 6, SHK_PH_COUNT = 7
+    SHK_PH_HALO = 5, SHK_PH_AMG_FINE = 6 /* finest-level smoothing SpMV, k_amg_post<true> */,
+    SHK_PH_AMG_COARSE = 7 /* every other multigrid kernel */, SHK_PH_COUNT = 8
 };
 typedef struct shk_profile {
     double ms[SHK_PH_COUNT];      /* summed launch durations per phase */

@@ -31,7 +31,7 @@ class shk_solve_info(C.Structure):
                 ("krylov_failed", C.c_int32), ("residual0", C.c_double), ("residual", C.c_double)]
 
 
-PHASES = ("assemble", "spmv", "vector", "update", "other", "halo", "precond")
+PHASES = ("assemble", "spmv", "vector", "update", "other", "halo", "amg_fine", "amg_coarse")
 PRECOND = dict(jacobi=0, amg=1)
 
 

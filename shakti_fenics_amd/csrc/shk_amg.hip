@@ -4,11 +4,12 @@
 // Hierarchy (built once on the host, shk_plan.cpp): aggregates are runs of 4 consecutive vertices of the
 // k-d order, prolongation is piecewise constant, coarse operators are Galerkin products whose sparsity is
 // fixed, so refreshing them after each assembly is one gather-sum kernel per level.  The coarsest level
-// (<= 64 rows) is inverted densely in LDS.  One V(1,1) cycle with damped Jacobi (omega = 0.7):
-//   down  k_amg_down   x = w D^-1 r; res = r - A x (x formed on the fly in the gather); r_c = P^T res via LDS
-//   up    k_amg_prolong x += P e_c ;  k_amg_post  x' = x + w D^-1 (r - A x)
-// All levels use SELL-64; a workgroup owns one aligned group of 4 slices = 256 rows, which by construction
-// contains all 4 members of each of its 64 aggregates.
+// (<= 64 rows) is inverted densely in LDS.  One V(0,2) cycle with damped Jacobi (omega = 0.7) -- on this
+// operator it needs as many BiCGStab iterations as V(1,1) and its smoothing kernels are plain SpMVs:
+//   down  k_amg_restrict   r_c = P^T r                       (no smoothing on the way down)
+//   up    k_amg_prolong    x = P e_c ;  k_amg_post x' = x + w D^-1 (r - A x), twice
+// All levels use SELL-64; an aligned group of 4 slices = 256 rows contains, by construction, all 4 members
+// of each of its 64 aggregates.
 #include "shk_device.h"
 
 namespace shk {
@@ -87,47 +88,17 @@ struct AmgSmoothArgs {
     const int* done;        // Krylov stop flag: once set, every later kernel of the queue returns at once
 };
 
-__global__ __launch_bounds__(kBlock) void k_amg_down(const AmgSmoothArgs a) {
-    __shared__ double resl[kBlock];
-    if (*a.done) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ngroups = (a.A.nslice + 3) >> 2;
-    for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        const int s = 4 * g + wave;
-        double res = 0.0;
-        if (s < a.A.nslice) {
-            const int base = __builtin_amdgcn_readfirstlane(a.A.ptr[s]);
-            const int width = (__builtin_amdgcn_readfirstlane(a.A.ptr[s + 1]) - base) >> 6;
-            const double* __restrict__ vp = a.vals + base + lane;
-            const int32_t* __restrict__ cp = a.A.col + base + lane;
-            double sum = 0.0;
-#pragma unroll 4
-            for (int k = 0; k < width; ++k) {
-                const int c = cp[k * kSlice];
-                sum += vp[k * kSlice] * (a.dinv[c] * a.r[c]);
-            }
-            const int row = s * kSlice + lane;
-            if (row < a.A.n_rows) {
-                const double ri = a.r[row];
-                a.xo[row] = a.omega * a.dinv[row] * ri;
-                res = ri - a.omega * sum;
-            }
-        }
-        resl[tid] = res;
-        __syncthreads();
-        if (tid < 64) {
-            const int I = 64 * g + tid;
-            if (I < a.n_coarse) {
-                double acc = 0.0;
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const int f = a.members[4 * I + m];
-                    if (f >= 0) acc += resl[f - 256 * g];
-                }
-                a.rc[I] = acc;
-            }
-        }
-        __syncthreads();
+__global__ __launch_bounds__(kBlock) void k_amg_restrict(int32_t n_coarse, const int32_t* __restrict__ members,
+                                                         const double* __restrict__ r, double* __restrict__ rc,
+                                                         const int* __restrict__ done) {
+    if (*done) return;
+    for (int32_t I = blockIdx.x * kBlock + threadIdx.x; I < n_coarse; I += gridDim.x * kBlock) {
+        const int4 m = reinterpret_cast<const int4*>(members)[I];
+        double acc = r[m.x];                      // every aggregate has at least one member
+        if (m.y >= 0) acc += r[m.y];
+        if (m.z >= 0) acc += r[m.z];
+        if (m.w >= 0) acc += r[m.w];
+        rc[I] = acc;
     }
 }
 
@@ -135,9 +106,11 @@ __global__ __launch_bounds__(kBlock) void k_amg_prolong(int32_t n, const int32_t
                                                         const double* __restrict__ ec, double* __restrict__ x,
                                                         const int* __restrict__ done) {
     if (*done) return;
-    for (int32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) x[i] += ec[agg[i]];
+    for (int32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) x[i] = ec[agg[i]];
 }
 
+// FINE only gives the finest level its own symbol, so that profilers report its launches separately
+template <bool FINE>
 __global__ __launch_bounds__(kBlock) void k_amg_post(const AmgSmoothArgs a) {
     if (*a.done) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -184,38 +157,46 @@ static DevSell level_sell(const Ctx* c, size_t l) {
     return DevSell{L.n, L.n, L.nslice, L.ptr, L.col, L.rowlen};
 }
 
-// z = M^-1 r : one V(1,1) cycle.  r and z have the fine level's length; r is not modified.
+// z = M^-1 r : one V(0,2) cycle.  r and z have the fine level's length; r is not modified.
 void amg_vcycle(Ctx* c, const double* rin, double* zout) {
-    PhaseTimer t(c, SHK_PH_PRECOND);
     const size_t nx = c->amg_xf.size();  // levels 0..nx-1 are sparse, level nx is the dense coarsest
     const int* done = &c->d_state->done;
     auto vals = [&](size_t l) { return l == 0 ? c->d_vals : c->amg_lv[l].vals; };
     auto dinv = [&](size_t l) { return l == 0 ? c->d_dinv : c->amg_lv[l].dinv; };
     auto rhs = [&](size_t l) -> const double* { return l == 0 ? rin : c->amg_lv[l].r; };
-    auto xw = [&](size_t l) { return l == 0 ? c->d_amg_x0 : c->amg_lv[l].x; };
-    auto xout = [&](size_t l) { return l == 0 ? zout : c->amg_lv[l].x2; };
-    for (size_t l = 0; l < nx; ++l) {
-        const AmgXfer& X = c->amg_xf[l];
-        AmgSmoothArgs a;
-        a.A = level_sell(c, l);
-        a.vals = vals(l); a.dinv = dinv(l); a.r = rhs(l); a.x = nullptr; a.xo = xw(l);
-        a.rc = X.dense ? c->d_cr : c->amg_lv[l + 1].r;
-        a.members = X.members; a.n_coarse = X.n_coarse; a.omega = kAmgOmega; a.done = done;
-        const int ngroups = (a.A.nslice + 3) / 4;
-        hipLaunchKernelGGL(k_amg_down, dim3(std::min(ngroups, 2048)), dim3(kBlock), 0, c->stream, a);
+    auto bufA = [&](size_t l) { return l == 0 ? zout : c->amg_lv[l].x2; };       // where the level's result lands
+    auto bufB = [&](size_t l) { return l == 0 ? c->d_amg_x0 : c->amg_lv[l].x; };
+    {
+        PhaseTimer t(c, SHK_PH_AMG_COARSE);
+        for (size_t l = 0; l < nx; ++l) {
+            const AmgXfer& X = c->amg_xf[l];
+            double* rc = X.dense ? c->d_cr : c->amg_lv[l + 1].r;
+            hipLaunchKernelGGL(k_amg_restrict, dim3(small_grid(X.n_coarse)), dim3(kBlock), 0, c->stream, X.n_coarse,
+                               X.members, rhs(l), rc, done);
+        }
+        hipLaunchKernelGGL(k_dense_apply, dim3(1), dim3(64), 0, c->stream, c->amg_xf[nx - 1].n_coarse, c->d_cinv,
+                           c->d_cr, c->d_cx, done);
     }
-    hipLaunchKernelGGL(k_dense_apply, dim3(1), dim3(64), 0, c->stream, c->amg_xf[nx - 1].n_coarse, c->d_cinv, c->d_cr,
-                       c->d_cx, done);
     for (size_t l = nx; l-- > 0;) {
         const AmgXfer& X = c->amg_xf[l];
         const double* ec = X.dense ? c->d_cx : c->amg_lv[l + 1].x2;
-        hipLaunchKernelGGL(k_amg_prolong, dim3(small_grid(X.n_fine)), dim3(kBlock), 0, c->stream, X.n_fine, X.agg, ec,
-                           xw(l), done);
+        {
+            PhaseTimer t(c, SHK_PH_AMG_COARSE);
+            hipLaunchKernelGGL(k_amg_prolong, dim3(small_grid(X.n_fine)), dim3(kBlock), 0, c->stream, X.n_fine, X.agg,
+                               ec, bufA(l), done);
+        }
         AmgSmoothArgs a;
         a.A = level_sell(c, l);
-        a.vals = vals(l); a.dinv = dinv(l); a.r = rhs(l); a.x = xw(l); a.xo = xout(l);
+        a.vals = vals(l); a.dinv = dinv(l); a.r = rhs(l);
         a.rc = nullptr; a.members = nullptr; a.n_coarse = 0; a.omega = kAmgOmega; a.done = done;
-        hipLaunchKernelGGL(k_amg_post, dim3(std::min((a.A.nslice + 3) / 4, 2048)), dim3(kBlock), 0, c->stream, a);
+        const dim3 g(std::min((a.A.nslice + 3) / 4, 2048));
+        for (int sweep = 0; sweep < 2; ++sweep) {
+            a.x = sweep == 0 ? bufA(l) : bufB(l);
+            a.xo = sweep == 0 ? bufB(l) : bufA(l);
+            PhaseTimer t(c, l == 0 ? SHK_PH_AMG_FINE : SHK_PH_AMG_COARSE);
+            if (l == 0) hipLaunchKernelGGL(k_amg_post<true>, g, dim3(kBlock), 0, c->stream, a);
+            else hipLaunchKernelGGL(k_amg_post<false>, g, dim3(kBlock), 0, c->stream, a);
+        }
     }
 }
 

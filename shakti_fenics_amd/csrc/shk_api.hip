@@ -401,7 +401,7 @@ int shk_get_csr(shk_ctx* ctx, int32_t* rowptr, int32_t* colidx, double* values) 
 // when chunk k's flag is read, so the GPU never idles; kernels after the stop return immediately.
 static int krylov_inner(Ctx* c, const double* rhs, int max_it, KrylovState* out) {
     krylov_init(c, rhs);
-    const int chunk = std::max(1, c->params.krylov_check_every);
+    const int chunk = c->profiling ? 1 : std::max(1, c->params.krylov_check_every);
     int it = 0, slot = 0;
     const int saved_max = c->params.krylov_max_it;
     c->params.krylov_max_it = max_it;
@@ -417,7 +417,13 @@ static int krylov_inner(Ctx* c, const double* rhs, int max_it, KrylovState* out)
     };
     hipError_t e = enqueue(slot);
     int rc = 0;
-    while (e == hipSuccess) {
+    while (e == hipSuccess && c->profiling) {  // profiling: no look-ahead, so every timed launch does real work
+        if ((e = hipEventSynchronize(c->poll_ev[slot])) != hipSuccess) break;
+        if (c->h_state[slot].done) { *out = c->h_state[slot]; break; }
+        if (it > max_it + 4 * chunk) { rc = fail("Krylov driver ran past max_it without a stop flag"); break; }
+        e = enqueue(slot);
+    }
+    while (e == hipSuccess && !c->profiling) {
         const int prev = slot;
         slot ^= 1;
         if ((e = enqueue(slot)) != hipSuccess) break;

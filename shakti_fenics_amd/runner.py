@@ -58,29 +58,39 @@ class SingleRunner:
         self.ctx.sync()
 
     def roofline(self, peak_gbs: float) -> dict:
-        """Per-launch hipEvent timing of one more step on the library's stream; the dominant kernel
-        is the CSR SpMV (two launches per BiCGStab iteration)."""
+        """Per-launch hipEvent timing of one more step on the library's stream.  The dominant kernel is the
+        SELL-64 SpMV in its two guises: `k_spmv` (2 launches per BiCGStab iteration) and, with the multigrid
+        preconditioner, the finest-level smoother `k_amg_post<true>` (4 launches per iteration)."""
         c = self.ctx
         c.profile_enable(True)
         c.profile_read(reset=True)
         info = self.step()
         prof = c.profile_read(reset=True)
         c.profile_enable(False)
-        nv, nnz = self.nv_global, self.nnz_global
-        # algorithmic bytes of one CSR SpMV launch: values 8 nnz + colidx 4 nnz + rowptr 4 (nv+1)
-        # + x 8 nv + y 8 nv   (SURVEY.md 8d: 104 nv at nnz = 7 nv)
-        spmv_bytes = 12 * nnz + 4 * (nv + 1) + 16 * nv
-        asm_bytes = 12 * self.ne_global + 16 * nv + 88 * nv + 8 * nv + 8 * nnz  # SURVEY.md 8d: 192 nv
-        ms = prof["spmv"]["ms"] / max(prof["spmv"]["launches"], 1)
-        ach = spmv_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        asm_ms = prof["assemble"]["ms"] / max(prof["assemble"]["launches"], 1)
+        nv, nnz, slices = self.nv_global, self.nnz_global, (self.nv_global + 63) // 64
+        # algorithmic bytes per launch (fp64 values, int32 indices), SURVEY.md 8d
+        b_spmv = 12 * nnz + 4 * (nv + 1) + 16 * nv                      # values, colidx, rowptr, x, y = 104 nv
+        b_post = 12 * nnz + 4 * (slices + 1) + 32 * nv                  # + r, 1/diag: x' = x + w D^-1 (r - A x)
+        b_asm = 12 * self.ne_global + 16 * nv + 88 * nv + 8 * nv + 8 * nnz  # 192 nv
+
+        def leg(phase, nbytes, name):
+            n = max(prof[phase]["launches"], 1)
+            ms = prof[phase]["ms"] / n
+            ach = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            return {"kernel": name, "avg_launch_ms": ms, "launches": prof[phase]["launches"],
+                    "bytes_per_launch": nbytes, "achieved": ach, "frac": ach / peak_gbs}
+
+        legs = {"spmv": leg("spmv", b_spmv, "k_spmv<1|2> (SELL-64 SpMV + fused BiCGStab dots)"),
+                "assemble": leg("assemble", b_asm, "k_assemble<true> (fused residual + Jacobian)")}
+        if prof["amg_fine"]["launches"]:
+            legs["amg_fine"] = leg("amg_fine", b_post, "k_amg_post<true> (finest-level multigrid smoother, SELL-64 SpMV)")
+        dom = max((k for k in legs if k != "assemble"), key=lambda k: prof[k]["ms"])
+        d = legs[dom]
         return {
-            "bound": "hbm", "kernel": "k_spmv (CSR-stream SpMV + fused BiCGStab dots)",
-            "achieved": ach, "peak": peak_gbs, "unit": "GB/s", "frac": ach / peak_gbs, "traffic": None,
-            "bytes_per_launch": spmv_bytes, "avg_launch_ms": ms, "launches": prof["spmv"]["launches"],
-            "assemble": {"avg_launch_ms": asm_ms, "bytes_per_launch": asm_bytes,
-                         "achieved": asm_bytes / (asm_ms * 1e-3) / 1e9 if asm_ms > 0 else 0.0,
-                         "launches": prof["assemble"]["launches"]},
+            "bound": "hbm", "kernel": d["kernel"], "achieved": d["achieved"], "peak": peak_gbs, "unit": "GB/s",
+            "frac": d["frac"], "traffic": None, "bytes_per_launch": d["bytes_per_launch"],
+            "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"],
+            "kernels": legs,
             "phase_ms": {k: v["ms"] for k, v in prof.items()},
             "profiled_step": {"newton_its": info.newton_its, "krylov_its": info.krylov_its},
         }
