@@ -38,7 +38,7 @@ typedef struct shk_params {
     double krylov_rtol, krylov_atol;
     int32_t newton_max_it;
     int32_t krylov_max_it;
-    int32_t krylov_check_every; /* iterations enqueued between host convergence polls */
+    int32_t krylov_check_every; /* iterations enqueued between host stop-flag polls; 0 = automatic */
     int32_t precond;            /* SHK_PC_JACOBI (north_star's solver, default) or SHK_PC_AMG */
 } shk_params;
 

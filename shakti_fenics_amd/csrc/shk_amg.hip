@@ -114,14 +114,23 @@ template <bool FINE>
 __global__ __launch_bounds__(kBlock) void k_amg_post(const AmgSmoothArgs a) {
     if (*a.done) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int s = blockIdx.x * 4 + wave; s < a.A.nslice; s += gridDim.x * 4) {
+    const GroupSweep sw = xcd_sweep((a.A.nslice + 3) >> 2, a.A.xcd_local);
+    for (int g = sw.begin; g < sw.end; g += sw.step) {
+        const int s = 4 * g + wave;
+        if (s >= a.A.nslice) break;
         const int base = __builtin_amdgcn_readfirstlane(a.A.ptr[s]);
         const int width = (__builtin_amdgcn_readfirstlane(a.A.ptr[s + 1]) - base) >> 6;
         const double* __restrict__ vp = a.vals + base + lane;
         const int32_t* __restrict__ cp = a.A.col + base + lane;
         double sum = 0.0;
+        if (a.A.xcd_local) {
 #pragma unroll 4
-        for (int k = 0; k < width; ++k) sum += vp[k * kSlice] * a.x[cp[k * kSlice]];
+            for (int k = 0; k < width; ++k) sum += vp[k * kSlice] * a.x[cp[k * kSlice]];
+        } else {  // matrix larger than the Infinity Cache: stream it non-temporally, keep x cached
+#pragma unroll 4
+            for (int k = 0; k < width; ++k)
+                sum += __builtin_nontemporal_load(vp + k * kSlice) * a.x[__builtin_nontemporal_load(cp + k * kSlice)];
+        }
         const int row = s * kSlice + lane;
         if (row < a.A.n_rows) a.xo[row] = a.x[row] + a.omega * a.dinv[row] * (a.r[row] - sum);
     }
@@ -154,7 +163,7 @@ void amg_numeric_setup(Ctx* c) {
 static DevSell level_sell(const Ctx* c, size_t l) {
     if (l == 0) return c->sell();
     const AmgLevel& L = c->amg_lv[l];
-    return DevSell{L.n, L.n, L.nslice, L.ptr, L.col, L.rowlen};
+    return DevSell{L.n, L.n, L.nslice, sell_fits_cache(L.slots), L.ptr, L.col, L.rowlen};
 }
 
 // z = M^-1 r : one V(0,2) cycle.  r and z have the fine level's length; r is not modified.

@@ -95,7 +95,7 @@ int shk_default_params(shk_params* p) {
     // DOLFINx NewtonSolver defaults (never overridden at solvers.py:52)
     p->newton_rtol = 1e-9; p->newton_atol = 1e-10; p->newton_relax = 1.0; p->newton_max_it = 50;
     // the reference solves each Newton system exactly (LU); the Krylov loop is driven to 1e-10
-    p->krylov_rtol = 1e-10; p->krylov_atol = 1e-50; p->krylov_max_it = 20000; p->krylov_check_every = 32;
+    p->krylov_rtol = 1e-10; p->krylov_atol = 1e-50; p->krylov_max_it = 20000; p->krylov_check_every = 0;
     p->precond = SHK_PC_JACOBI;
     return 0;
 }
@@ -267,7 +267,7 @@ int shk_set_params(shk_ctx* ctx, const shk_params* p) {
     CHECK_CTX(ctx);
     if (!p) return fail("null params");
     if (!(p->g > 0 && p->rho_i > 0 && p->rho_w > 0 && p->nu > 0 && p->Lh > 0)) return fail("non-positive constant");
-    if (p->newton_max_it < 0 || p->krylov_max_it < 1 || p->krylov_check_every < 1) return fail("bad iteration limits");
+    if (p->newton_max_it < 0 || p->krylov_max_it < 1 || p->krylov_check_every < 0) return fail("bad iteration limits");
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (p->precond != SHK_PC_JACOBI && p->precond != SHK_PC_AMG) return fail("unknown preconditioner id");
     if (p->precond == SHK_PC_AMG && c->amg_xf.empty())
@@ -401,7 +401,10 @@ int shk_get_csr(shk_ctx* ctx, int32_t* rowptr, int32_t* colidx, double* values) 
 // when chunk k's flag is read, so the GPU never idles; kernels after the stop return immediately.
 static int krylov_inner(Ctx* c, const double* rhs, int max_it, KrylovState* out) {
     krylov_init(c, rhs);
-    const int chunk = c->profiling ? 1 : std::max(1, c->params.krylov_check_every);
+    // iterations enqueued per stop-flag poll: 0 = auto (a multigrid iteration is ~90 launches: poll often)
+    const int chunk = c->profiling ? 1
+                      : c->params.krylov_check_every > 0 ? c->params.krylov_check_every
+                      : c->use_amg ? 2 : 16;
     int it = 0, slot = 0;
     const int saved_max = c->params.krylov_max_it;
     c->params.krylov_max_it = max_it;
@@ -715,7 +718,8 @@ int shk_time_kernel(shk_ctx* ctx, int32_t phase, int32_t reps, double dt, double
     CHECK_CTX(ctx);
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (reps < 1 || !avg_ms) return fail("bad arguments");
-    if (phase != SHK_PH_ASSEMBLE && phase != SHK_PH_SPMV) return fail("only ASSEMBLE and SPMV can be timed");
+    if (phase != SHK_PH_ASSEMBLE && phase != SHK_PH_SPMV && phase != SHK_PH_OTHER)
+        return fail("only ASSEMBLE, SPMV and OTHER (streaming-read calibration) can be timed");
     if (phase == SHK_PH_SPMV && !c->assembled) return fail("no assembled system: call shk_assemble first");
     HIPCHK(hipSetDevice(c->device));
     const bool was = c->profiling;
@@ -725,7 +729,8 @@ int shk_time_kernel(shk_ctx* ctx, int32_t phase, int32_t reps, double dt, double
     HIPCHK(hipEventCreate(&b));
     auto once = [&]() {
         if (phase == SHK_PH_ASSEMBLE) launch_assemble(c, dt);
-        else launch_spmv_plain(c, c->d_vals, c->d_p, c->d_v);
+        else if (phase == SHK_PH_SPMV) launch_spmv_plain(c, c->d_vals, c->d_p, c->d_v);
+        else launch_stream_read(c);  // k_norm2 over the value array: exactly 8 * slots bytes, 8 B per lane
     };
     once();  // warm
     HIPCHK(hipEventRecord(a, c->stream));

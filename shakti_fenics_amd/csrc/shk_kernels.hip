@@ -316,14 +316,23 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const SpmvArgs a) {
     }
     const int lane = tid & 63, wave = tid >> 6;
     double d0 = 0.0, d1 = 0.0, d2 = 0.0;
-    for (int s = blockIdx.x * (kBlock / kSlice) + wave; s < a.A.nslice; s += gridDim.x * (kBlock / kSlice)) {
+    const GroupSweep sw = xcd_sweep((a.A.nslice + 3) >> 2, a.A.xcd_local);
+    for (int g = sw.begin; g < sw.end; g += sw.step) {
+        const int s = 4 * g + wave;
+        if (s >= a.A.nslice) break;
         const int base = __builtin_amdgcn_readfirstlane(a.A.ptr[s]);
         const int width = (__builtin_amdgcn_readfirstlane(a.A.ptr[s + 1]) - base) >> 6;
         const double* __restrict__ vp = a.vals + base + lane;
         const int32_t* __restrict__ cp = a.A.col + base + lane;
         double sum = 0.0;
+        if (a.A.xcd_local) {
 #pragma unroll 4
-        for (int k = 0; k < width; ++k) sum += vp[k * kSlice] * a.x[cp[k * kSlice]];
+            for (int k = 0; k < width; ++k) sum += vp[k * kSlice] * a.x[cp[k * kSlice]];
+        } else {  // matrix larger than the Infinity Cache: stream it non-temporally, keep x cached
+#pragma unroll 4
+            for (int k = 0; k < width; ++k)
+                sum += __builtin_nontemporal_load(vp + k * kSlice) * a.x[__builtin_nontemporal_load(cp + k * kSlice)];
+        }
         const int row = s * kSlice + lane;
         if (row < a.A.n_rows) {
             a.y[row] = sum;
@@ -367,6 +376,13 @@ __global__ __launch_bounds__(kBlock) void k_norm2(int64_t n, const double* __res
         a += x[i] * x[i];
     a = block_sum(a, sh4);
     if (threadIdx.x == 0) part[blockIdx.x] = a;
+}
+
+// Calibration of the HBM counters: a pure streaming read of known size (8 B per lane, like the SpMV's
+// value stream).
+void launch_stream_read(Ctx* c) {
+    hipLaunchKernelGGL(k_norm2, dim3(c->grid), dim3(kBlock), 0, c->stream, c->slots, c->d_vals,
+                       c->d_part + P_AUX * kMaxParts);
 }
 
 void launch_norm2(Ctx* c, const double* x, double* partials) {
