@@ -44,7 +44,12 @@ typedef struct shk_params {
 
 /* Right preconditioner of BiCGStab.  JACOBI is folded into the matrix (A D^-1).  AMG = one V(1,1) cycle of a
  * static-pattern aggregation multigrid (of the owned diagonal block on subdomain contexts). */
-enum shk_precond { SHK_PC_JACOBI = 0, SHK_PC_AMG = 1 };
+enum shk_precond {
+    SHK_PC_JACOBI = 0,
+    SHK_PC_AMG = 1,        /* on a communicator of > 1 subdomains: distributed hierarchy, built collectively by the
+                              first shk_set_params that selects it */
+    SHK_PC_AMG_LOCAL = 2   /* multigrid of each subdomain's own diagonal block (additive Schwarz, no communication) */
+};
 
 enum shk_field {
     SHK_N = 0,       /* effective pressure, the Newton unknown          (solvers.py:129) */
@@ -108,10 +113,12 @@ int shk_set_halo(shk_ctx* ctx, int32_t n_nbr, const int32_t* nbr_rank, const int
  * whatever bootstrap the host has, e.g. torch.distributed broadcast). */
 int shk_comm_unique_id(void* id128);
 int shk_comm_init_rccl(shk_ctx* ctx, int32_t rank, int32_t nranks, const void* id128);
-/* Host-staged transport through caller callbacks (gloo / MPI / tests).  exchange(user, send, recv): `send`
- * holds the packed values for all neighbours (send_ptr layout), fill `recv` (recv_ptr layout);
+/* Host-staged transport through caller callbacks (gloo / MPI / tests).  exchange(...): for neighbour k send
+ * send[send_ptr[k] .. send_ptr[k+1]) to rank nbr[k] and receive recv[recv_ptr[k] .. recv_ptr[k+1]) from it (the
+ * layout is passed on every call because multigrid levels exchange with their own, smaller plans);
  * allreduce(user, buf, n): in-place element-wise sum over ranks.  Both return 0 on success. */
-typedef int (*shk_exchange_fn)(void* user, const double* send, double* recv);
+typedef int (*shk_exchange_fn)(void* user, int32_t n_nbr, const int32_t* nbr, const double* send,
+                               const int64_t* send_ptr, double* recv, const int64_t* recv_ptr);
 typedef int (*shk_allreduce_fn)(void* user, double* buf, int64_t n);
 int shk_comm_init_callbacks(shk_ctx* ctx, int32_t rank, int32_t nranks, shk_exchange_fn exchange,
                             shk_allreduce_fn allreduce, void* user);

@@ -32,7 +32,7 @@ class shk_solve_info(C.Structure):
 
 
 PHASES = ("assemble", "spmv", "vector", "update", "other", "halo", "amg_fine", "amg_coarse")
-PRECOND = dict(jacobi=0, amg=1)
+PRECOND = dict(jacobi=0, amg=1, amg_local=2)
 
 
 class shk_profile(C.Structure):
@@ -51,7 +51,8 @@ EXPORTS = (
     "shk_comm_init_rccl", "shk_comm_init_callbacks", "shk_halo_update",
 )
 
-EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double),
+                          C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64))
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64)
 
 _lib = None
@@ -258,16 +259,19 @@ class ShaktiHip:
         self._check(self.lib.shk_comm_init_rccl(self._h, rank, nranks, C.cast(buf, C.c_void_p)))
 
     def comm_init_callbacks(self, rank: int, nranks: int, exchange, allreduce):
-        """exchange(send: np.ndarray, recv: np.ndarray) and allreduce(buf: np.ndarray) operate in place on
-        host views laid out by the halo plan; exceptions are reported as transport failures."""
-        nbr, sp, si, rp = self._halo
-        nsend, nrecv = int(sp[-1]), int(rp[-1])
+        """exchange(nbr, send, send_ptr, recv, recv_ptr) fills `recv` in place (NumPy views of the staging
+        buffers; neighbour k sends send[send_ptr[k]:send_ptr[k+1]] and receives recv[recv_ptr[k]:recv_ptr[k+1]]);
+        allreduce(buf) sums `buf` over ranks in place.  Exceptions are reported as transport failures."""
 
-        def _ex(user, send_p, recv_p):
+        def _ex(user, n_nbr, nbr_p, send_p, sp_p, recv_p, rp_p):
             try:
-                send = np.ctypeslib.as_array(send_p, shape=(max(nsend, 1),))[:nsend]
-                recv = np.ctypeslib.as_array(recv_p, shape=(max(nrecv, 1),))[:nrecv]
-                exchange(send, recv)
+                n = int(n_nbr)
+                nbr = np.ctypeslib.as_array(nbr_p, shape=(max(n, 1),))[:n]
+                sp = np.ctypeslib.as_array(sp_p, shape=(n + 1,))
+                rp = np.ctypeslib.as_array(rp_p, shape=(n + 1,))
+                send = np.ctypeslib.as_array(send_p, shape=(max(int(sp[-1]), 1),))[: int(sp[-1])]
+                recv = np.ctypeslib.as_array(recv_p, shape=(max(int(rp[-1]), 1),))[: int(rp[-1])]
+                exchange(nbr, send, sp, recv, rp)
                 return 0
             except Exception:  # pragma: no cover - surfaced through the C error path
                 import traceback

@@ -62,15 +62,53 @@ __global__ __launch_bounds__(kBlock) void k_dense_invert(int n, const double* __
     for (int e = tid; e < n * n; e += kBlock) inv[e] = M[(e / n) * 64 + (e % n)];
 }
 
-__global__ __launch_bounds__(64) void k_dense_apply(int n, const double* __restrict__ inv,
+// x[i] = sum_j inv[(row0 + i) * ncols + j] * r[j] for my n rows of the (possibly shared) coarsest operator
+__global__ __launch_bounds__(64) void k_dense_apply(int n, int row0, int ncols, const double* __restrict__ inv,
                                                     const double* __restrict__ r, double* __restrict__ x,
                                                     const int* __restrict__ done) {
     if (*done) return;
     const int i = threadIdx.x;
     if (i < n) {
         double a = 0.0;
-        for (int j = 0; j < n; ++j) a += inv[i * n + j] * r[j];
+        const double* row = inv + (size_t)(row0 + i) * ncols;
+        for (int j = 0; j < ncols; ++j) a += row[j] * r[j];
         x[i] = a;
+    }
+}
+
+// Shared coarsest level: every subdomain contributes its slice of the right-hand side (zeros elsewhere); the
+// element-wise sum over subdomains is then the gathered vector.
+__global__ __launch_bounds__(kBlock) void k_coarse_scatter(int n, int row0, int ncols, const double* __restrict__ rc,
+                                                           double* __restrict__ rglob, const int* __restrict__ done) {
+    if (*done) return;
+    for (int j = threadIdx.x; j < ncols; j += kBlock) rglob[j] = (j >= row0 && j < row0 + n) ? rc[j - row0] : 0.0;
+}
+
+// Gauss-Jordan inverse in global memory for the shared coarsest operator (n <= 1024), one workgroup of 1024.
+__global__ __launch_bounds__(1024) void k_dense_invert_big(int n, const double* __restrict__ A, double* __restrict__ M,
+                                                           double* __restrict__ mult) {
+    const int tid = threadIdx.x;
+    for (int e = tid; e < n * n; e += 1024) M[e] = A[e];
+    __syncthreads();
+    for (int p = 0; p < n; ++p) {
+        const double piv = M[(size_t)p * n + p];
+        const double d = (piv != 0.0) ? 1.0 / piv : 0.0;
+        __syncthreads();
+        if (tid == 0) M[(size_t)p * n + p] = 1.0;
+        __syncthreads();
+        for (int j = tid; j < n; j += 1024) {
+            M[(size_t)p * n + j] *= d;
+            mult[j] = (j != p) ? M[(size_t)j * n + p] : 0.0;
+        }
+        __syncthreads();
+        for (int j = tid; j < n; j += 1024)
+            if (j != p) M[(size_t)j * n + p] = 0.0;
+        __syncthreads();
+        for (int e = tid; e < n * n; e += 1024) {
+            const int i = e / n, j = e % n;
+            if (i != p) M[e] -= mult[i] * M[(size_t)p * n + j];
+        }
+        __syncthreads();
     }
 }
 
@@ -139,18 +177,30 @@ __global__ __launch_bounds__(kBlock) void k_amg_post(const AmgSmoothArgs a) {
 static int small_grid(int64_t n) { return (int)std::min<int64_t>(1024, std::max<int64_t>(1, (n + kBlock - 1) / kBlock)); }
 
 // Refresh the coarse operators from the Jacobian just assembled (d_vals, d_dinv).
-void amg_numeric_setup(Ctx* c) {
+hipError_t amg_numeric_setup(Ctx* c) {
+    AmgHierarchy& H = *c->amg;
     PhaseTimer t(c, SHK_PH_OTHER);
     const double* fine = c->d_vals;
-    for (size_t l = 0; l < c->amg_xf.size(); ++l) {
-        const AmgXfer& X = c->amg_xf[l];
+    for (size_t l = 0; l < H.xf.size(); ++l) {
+        const AmgXfer& X = H.xf[l];
         if (X.dense) {
-            const int64_t ns = (int64_t)X.n_coarse * X.n_coarse;
-            hipLaunchKernelGGL(k_galerkin, dim3(small_grid(ns)), dim3(kBlock), 0, c->stream, ns, X.gptr, X.glist, fine,
-                               c->d_cdense);
-            hipLaunchKernelGGL(k_dense_invert, dim3(1), dim3(kBlock), 0, c->stream, X.n_coarse, c->d_cdense, c->d_cinv);
+            const int64_t ns = (int64_t)X.n_coarse * X.n_coarse_cols;  // my rows of the coarsest operator
+            if (H.distributed) {
+                const size_t all = (size_t)H.n_glob * H.n_glob;
+                hipError_t e = hipMemsetAsync(H.cdense, 0, all * sizeof(double), c->stream);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(k_galerkin, dim3(small_grid(ns)), dim3(kBlock), 0, c->stream, ns, X.gptr, X.glist,
+                                   fine, H.cdense + (size_t)H.offset * H.n_glob);
+                if ((e = allreduce_buffer(c, H.cdense, H.cdense, all)) != hipSuccess) return e;
+                hipLaunchKernelGGL(k_dense_invert_big, dim3(1), dim3(1024), 0, c->stream, H.n_glob, H.cdense, H.cinv,
+                                   H.cglob);
+            } else {
+                hipLaunchKernelGGL(k_galerkin, dim3(small_grid(ns)), dim3(kBlock), 0, c->stream, ns, X.gptr, X.glist,
+                                   fine, H.cdense);
+                hipLaunchKernelGGL(k_dense_invert, dim3(1), dim3(kBlock), 0, c->stream, X.n_coarse, H.cdense, H.cinv);
+            }
         } else {
-            AmgLevel& L = c->amg_lv[l + 1];
+            AmgLevel& L = H.lv[l + 1];
             hipLaunchKernelGGL(k_galerkin, dim3(small_grid(L.slots)), dim3(kBlock), 0, c->stream, L.slots, X.gptr,
                                X.glist, fine, L.vals);
             hipLaunchKernelGGL(k_diag_inv, dim3(small_grid(L.n)), dim3(kBlock), 0, c->stream, L.n, L.diag_slot, L.vals,
@@ -158,55 +208,213 @@ void amg_numeric_setup(Ctx* c) {
             fine = L.vals;
         }
     }
+    return hipSuccess;
 }
 
-static DevSell level_sell(const Ctx* c, size_t l) {
+static DevSell level_sell(const Ctx* c, const AmgHierarchy& H, size_t l) {
     if (l == 0) return c->sell();
-    const AmgLevel& L = c->amg_lv[l];
-    return DevSell{L.n, L.n, L.nslice, sell_fits_cache(L.slots), L.ptr, L.col, L.rowlen};
+    const AmgLevel& L = H.lv[l];
+    return DevSell{L.n, L.n_cols, L.nslice, sell_fits_cache(L.slots), L.ptr, L.col, L.rowlen};
 }
 
 // z = M^-1 r : one V(0,2) cycle.  r and z have the fine level's length; r is not modified.
-void amg_vcycle(Ctx* c, const double* rin, double* zout) {
-    const size_t nx = c->amg_xf.size();  // levels 0..nx-1 are sparse, level nx is the dense coarsest
+hipError_t amg_vcycle(Ctx* c, const double* rin, double* zout) {
+    AmgHierarchy& H = *c->amg;
+    const size_t nx = H.xf.size();  // levels 0..nx-1 are sparse, level nx is the dense coarsest
     const int* done = &c->d_state->done;
-    auto vals = [&](size_t l) { return l == 0 ? c->d_vals : c->amg_lv[l].vals; };
-    auto dinv = [&](size_t l) { return l == 0 ? c->d_dinv : c->amg_lv[l].dinv; };
-    auto rhs = [&](size_t l) -> const double* { return l == 0 ? rin : c->amg_lv[l].r; };
-    auto bufA = [&](size_t l) { return l == 0 ? zout : c->amg_lv[l].x2; };       // where the level's result lands
-    auto bufB = [&](size_t l) { return l == 0 ? c->d_amg_x0 : c->amg_lv[l].x; };
+    hipError_t e;
+    auto vals = [&](size_t l) { return l == 0 ? c->d_vals : H.lv[l].vals; };
+    auto dinv = [&](size_t l) { return l == 0 ? c->d_dinv : H.lv[l].dinv; };
+    auto rhs = [&](size_t l) -> const double* { return l == 0 ? rin : H.lv[l].r; };
+    auto bufA = [&](size_t l) { return l == 0 ? zout : H.lv[l].x2; };       // where the level's result lands
+    auto bufB = [&](size_t l) { return l == 0 ? H.x0 : H.lv[l].x; };
+    if (c->n_loc > c->n_own && !(H.distributed && H.halo_levels > 0)) {
+        // block-local smoothing on the finest level: the output vector's ghost entries (left over from the Krylov
+        // loop's own exchange) must read as zero, or the preconditioner would change from call to call
+        if ((e = hipMemsetAsync(zout + c->n_own, 0, (size_t)(c->n_loc - c->n_own) * sizeof(double), c->stream)) != hipSuccess)
+            return e;
+    }
     {
         PhaseTimer t(c, SHK_PH_AMG_COARSE);
         for (size_t l = 0; l < nx; ++l) {
-            const AmgXfer& X = c->amg_xf[l];
-            double* rc = X.dense ? c->d_cr : c->amg_lv[l + 1].r;
+            const AmgXfer& X = H.xf[l];
+            double* rc = X.dense ? H.cr : H.lv[l + 1].r;
             hipLaunchKernelGGL(k_amg_restrict, dim3(small_grid(X.n_coarse)), dim3(kBlock), 0, c->stream, X.n_coarse,
                                X.members, rhs(l), rc, done);
         }
-        hipLaunchKernelGGL(k_dense_apply, dim3(1), dim3(64), 0, c->stream, c->amg_xf[nx - 1].n_coarse, c->d_cinv,
-                           c->d_cr, c->d_cx, done);
+    }
+    const AmgXfer& XL = H.xf[nx - 1];
+    if (H.distributed) {
+        hipLaunchKernelGGL(k_coarse_scatter, dim3(1), dim3(kBlock), 0, c->stream, XL.n_coarse, H.offset, H.n_glob, H.cr,
+                           H.cglob, done);
+        if ((e = allreduce_buffer(c, H.cglob, H.cglob, (size_t)H.n_glob)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_dense_apply, dim3(1), dim3(64), 0, c->stream, XL.n_coarse, H.offset, H.n_glob, H.cinv,
+                           H.cglob, H.cx, done);
+    } else {
+        PhaseTimer t(c, SHK_PH_AMG_COARSE);
+        hipLaunchKernelGGL(k_dense_apply, dim3(1), dim3(64), 0, c->stream, XL.n_coarse, 0, XL.n_coarse, H.cinv, H.cr,
+                           H.cx, done);
     }
     for (size_t l = nx; l-- > 0;) {
-        const AmgXfer& X = c->amg_xf[l];
-        const double* ec = X.dense ? c->d_cx : c->amg_lv[l + 1].x2;
+        const AmgXfer& X = H.xf[l];
+        const double* ec = X.dense ? H.cx : H.lv[l + 1].x2;
         {
             PhaseTimer t(c, SHK_PH_AMG_COARSE);
             hipLaunchKernelGGL(k_amg_prolong, dim3(small_grid(X.n_fine)), dim3(kBlock), 0, c->stream, X.n_fine, X.agg,
                                ec, bufA(l), done);
         }
         AmgSmoothArgs a;
-        a.A = level_sell(c, l);
+        a.A = level_sell(c, H, l);
         a.vals = vals(l); a.dinv = dinv(l); a.r = rhs(l);
         a.rc = nullptr; a.members = nullptr; a.n_coarse = 0; a.omega = kAmgOmega; a.done = done;
         const dim3 g(std::min((a.A.nslice + 3) / 4, 2048));
+        const bool halo = H.distributed && (int)l < H.halo_levels;
         for (int sweep = 0; sweep < 2; ++sweep) {
-            a.x = sweep == 0 ? bufA(l) : bufB(l);
+            double* xin = sweep == 0 ? bufA(l) : bufB(l);
+            a.x = xin;
             a.xo = sweep == 0 ? bufB(l) : bufA(l);
+            // distributed smoothing: the sweep needs the neighbours' current iterate on the ghost columns
+            // (without the exchange the ghost entries stay zero = block-local smoothing on that level)
+            if (halo && (e = halo_exchange_plan(c, c->comm.plans[H.plan_of[l]], xin)) != hipSuccess) return e;
             PhaseTimer t(c, l == 0 ? SHK_PH_AMG_FINE : SHK_PH_AMG_COARSE);
             if (l == 0) hipLaunchKernelGGL(k_amg_post<true>, g, dim3(kBlock), 0, c->stream, a);
             else hipLaunchKernelGGL(k_amg_post<false>, g, dim3(kBlock), 0, c->stream, a);
         }
     }
+    return hipSuccess;
+}
+
+// ------------------------------------------------------------------ distributed setup (collective)
+// One integer per row of a level travels as a double through that level's halo plan.
+static hipError_t exchange_ids(Ctx* c, const HaloPlan& P, int64_t n_ghost, const std::vector<int32_t>& owned,
+                               std::vector<int32_t>& ghost) {
+    std::vector<double> buf((size_t)(P.n_own + n_ghost), -1.0);
+    for (int64_t i = 0; i < P.n_own; ++i) buf[i] = (double)owned[i];
+    hipError_t e = hipMemcpyAsync(c->d_io, buf.data(), buf.size() * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) return e;
+    if ((e = halo_exchange_plan(c, P, c->d_io)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(buf.data(), c->d_io, buf.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
+        return e;
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return e;
+    ghost.resize((size_t)n_ghost);
+    for (int64_t g = 0; g < n_ghost; ++g) ghost[g] = (int32_t)buf[P.n_own + g];
+    return hipSuccess;
+}
+
+static hipError_t allgather_int(Ctx* c, int32_t mine, std::vector<int32_t>& all) {
+    const int R = c->comm.nranks;
+    std::vector<double> buf((size_t)R, 0.0);
+    buf[c->comm.rank] = (double)mine;
+    double* d = c->d_io;
+    hipError_t e = hipMemcpyAsync(d, buf.data(), R * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) return e;
+    if ((e = allreduce_buffer(c, d, d, (size_t)R)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(buf.data(), d, R * sizeof(double), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return e;
+    all.resize(R);
+    for (int r = 0; r < R; ++r) all[r] = (int32_t)buf[r];
+    return hipSuccess;
+}
+
+// Build the distributed hierarchy: aggregates are local (runs of 4 owned rows in k-d order), but every level
+// keeps its ghost columns (the neighbours' aggregates), so the Galerkin operators are exactly those of the
+// undecomposed matrix and a V-cycle with per-level ghost exchanges is the same operator as on one GPU.
+// Every subdomain must call this at the same time (it exchanges aggregate ids level by level).
+int amg_setup_distributed(Ctx* c, std::string& err) {
+    Comm& m = c->comm;
+    if (m.kind == Comm::NONE || m.plans.empty()) { err = "no communicator"; return -1; }
+    if (c->plan.krank.size() != (size_t)c->n_own) { err = "k-d ranks unavailable"; return -1; }
+    const int R = m.nranks, me = m.rank;
+    if ((size_t)2 * c->n_loc < (size_t)R) { err = "too many ranks for the staging buffer"; return -1; }
+    AmgHierarchy& H = c->amg_dist;
+    H.distributed = true;
+    if (const char* s = getenv("SHK_AMG_HALO_LEVELS")) H.halo_levels = std::max(0, atoi(s));
+    std::vector<AmgLevelPlan> plans;
+    plans.reserve(40);
+    const SellPattern* Af = &c->plan.A;
+    int64_t n_own = c->n_own, n_ghost = c->n_loc - c->n_own;
+    std::vector<int32_t> agg((size_t)n_own);
+    for (int64_t i = 0; i < n_own; ++i) agg[i] = c->plan.krank[i] / 4;
+    size_t cur_plan = 0;  // index into m.plans of the current level's halo plan
+    H.plan_of.clear();
+    hipError_t e;
+    for (int level = 0; level < 40; ++level) {
+        std::vector<int32_t> all_n;
+        if ((e = allgather_int(c, (int32_t)n_own, all_n)) != hipSuccess) { err = hipGetErrorString(e); return -1; }
+        int32_t maxn = 0;
+        for (int32_t v : all_n) maxn = std::max(maxn, v);
+        if (maxn <= 64) { err = "subdomains of <= 64 vertices: nothing to coarsen"; return -1; }
+        std::vector<int32_t> all_nc(R), offs(R + 1, 0);
+        int32_t maxnc = 0;
+        for (int r = 0; r < R; ++r) {
+            all_nc[r] = (all_n[r] + 3) / 4;
+            maxnc = std::max(maxnc, all_nc[r]);
+            offs[r + 1] = offs[r] + all_nc[r];
+        }
+        const bool next_dense = maxnc <= 64;
+        if (next_dense && offs[R] > 1024) { err = "shared coarsest level larger than 1024 rows (too many subdomains)"; return -1; }
+        const int32_t nc_own = all_nc[me];
+        const HaloPlan& P = m.plans[cur_plan];
+        std::vector<int32_t> gagg;
+        if ((e = exchange_ids(c, P, n_ghost, agg, gagg)) != hipSuccess) { err = hipGetErrorString(e); return -1; }
+        // coarse ghosts per neighbour = sorted unique aggregate ids of that neighbour's ghosts; coarse sends =
+        // sorted unique aggregates of what I send it (the two sides derive the same ordered lists)
+        HaloPlan CP;
+        CP.n_own = nc_own;
+        CP.nbr = P.nbr;
+        CP.send_ptr.assign(1, 0);
+        CP.recv_ptr.assign(1, 0);
+        std::vector<int32_t> colmap((size_t)(n_own + n_ghost), -1);
+        for (int64_t i = 0; i < n_own; ++i) colmap[i] = next_dense ? offs[me] + agg[i] : agg[i];
+        int64_t cghost = 0;
+        for (size_t k = 0; k < P.nbr.size(); ++k) {
+            std::vector<int32_t> ids(gagg.begin() + P.recv_ptr[k], gagg.begin() + P.recv_ptr[k + 1]);
+            std::sort(ids.begin(), ids.end());
+            ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+            for (int64_t g = P.recv_ptr[k]; g < P.recv_ptr[k + 1]; ++g) {
+                if (gagg[g] < 0 || gagg[g] >= all_nc[P.nbr[k]]) { err = "inconsistent aggregate id from a neighbour"; return -1; }
+                const int32_t pos = (int32_t)(std::lower_bound(ids.begin(), ids.end(), gagg[g]) - ids.begin());
+                colmap[n_own + g] = next_dense ? offs[P.nbr[k]] + gagg[g] : (int32_t)(nc_own + cghost + pos);
+            }
+            cghost += (int64_t)ids.size();
+            CP.recv_ptr.push_back(cghost);
+            std::vector<int32_t> sids;
+            for (int64_t q = P.send_ptr[k]; q < P.send_ptr[k + 1]; ++q) sids.push_back(agg[P.h_send_idx[q]]);
+            std::sort(sids.begin(), sids.end());
+            sids.erase(std::unique(sids.begin(), sids.end()), sids.end());
+            CP.h_send_idx.insert(CP.h_send_idx.end(), sids.begin(), sids.end());
+            CP.send_ptr.push_back((int64_t)CP.h_send_idx.size());
+        }
+        plans.emplace_back();
+        const int32_t ncols = next_dense ? offs[R] : (int32_t)(nc_own + cghost);
+        std::string perr = coarsen(*Af, agg, colmap, nc_own, ncols, next_dense, plans.back());
+        if (!perr.empty()) { err = perr; return -1; }
+        H.plan_of.push_back((int)cur_plan);
+        if (next_dense) {
+            H.n_glob = offs[R];
+            H.offset = offs[me];
+            break;
+        }
+        // install the coarse level's halo plan on the device
+        if (!CP.h_send_idx.empty()) {
+            void* q = nullptr;
+            if ((e = hipMalloc(&q, CP.h_send_idx.size() * sizeof(int32_t))) != hipSuccess) { err = hipGetErrorString(e); return -1; }
+            c->allocs.push_back(q);
+            CP.d_send_idx = reinterpret_cast<int32_t*>(q);
+            if ((e = hipMemcpy(q, CP.h_send_idx.data(), CP.h_send_idx.size() * sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess) {
+                err = hipGetErrorString(e); return -1;
+            }
+        }
+        m.plans.push_back(std::move(CP));
+        cur_plan = m.plans.size() - 1;
+        Af = &plans.back().Ac;
+        n_own = nc_own;
+        n_ghost = cghost;
+        agg.resize((size_t)n_own);
+        for (int64_t I = 0; I < n_own; ++I) agg[I] = (int32_t)(I / 4);
+    }
+    if ((e = amg_upload(c, plans, H, c->n_loc)) != hipSuccess) { err = hipGetErrorString(e); return -1; }
+    return 0;
 }
 
 }  // namespace shk

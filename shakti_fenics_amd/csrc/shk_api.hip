@@ -80,6 +80,51 @@ static int set_quadrature(Ctx* c, int nq, const double* xyw) {
     return 0;
 }
 
+namespace shk {
+hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H, int64_t n_loc0) {
+    hipError_t e;
+    const size_t nx = plans.size();
+    H.xf.resize(nx);
+    H.lv.resize(nx);  // [0] unused; sparse levels 1 .. nx-1
+    for (size_t l = 0; l < nx; ++l) {
+        AmgLevelPlan& LP = plans[l];
+        AmgXfer& X = H.xf[l];
+        X.n_fine = LP.n_fine; X.n_coarse = LP.n_coarse; X.n_coarse_cols = LP.n_coarse_cols; X.dense = LP.dense;
+        if ((e = upload(c, &X.agg, LP.agg)) != hipSuccess) return e;
+        if ((e = upload(c, &X.members, LP.members)) != hipSuccess) return e;
+        if ((e = upload(c, &X.gptr, LP.gptr)) != hipSuccess) return e;
+        if ((e = upload(c, &X.glist, LP.glist)) != hipSuccess) return e;
+        if (!LP.dense) {
+            if (l + 1 >= nx) return hipErrorInvalidValue;  // a hierarchy must end on a dense level
+            AmgLevel& L = H.lv[l + 1];
+            L.n = LP.Ac.n_rows; L.n_cols = LP.Ac.n_cols; L.nslice = LP.Ac.nslice; L.slots = LP.Ac.slots;
+            if ((e = upload(c, &L.ptr, LP.Ac.ptr)) != hipSuccess) return e;
+            if ((e = upload(c, &L.col, LP.Ac.col)) != hipSuccess) return e;
+            if ((e = upload(c, &L.rowlen, LP.Ac.rowlen)) != hipSuccess) return e;
+            if ((e = upload(c, &L.diag_slot, LP.diag_slot)) != hipSuccess) return e;
+            const size_t nr = std::max<size_t>((size_t)L.nslice * kSlice, (size_t)L.n_cols);
+            if ((e = dev_alloc(c, &L.vals, (size_t)L.slots)) != hipSuccess) return e;
+            double** vs[] = {&L.dinv, &L.x, &L.x2, &L.r};
+            for (double** v : vs) {
+                if ((e = dev_alloc(c, v, nr)) != hipSuccess) return e;
+                if ((e = hipMemset(*v, 0, nr * sizeof(double))) != hipSuccess) return e;
+            }
+        } else {
+            const size_t rows = H.distributed ? (size_t)H.n_glob : (size_t)LP.n_coarse;
+            const size_t cols = (size_t)LP.n_coarse_cols;
+            if ((e = dev_alloc(c, &H.cdense, rows * cols)) != hipSuccess) return e;
+            if ((e = dev_alloc(c, &H.cinv, rows * cols)) != hipSuccess) return e;
+            if ((e = dev_alloc(c, &H.cr, std::max<size_t>(64, cols))) != hipSuccess) return e;
+            if ((e = dev_alloc(c, &H.cx, 64)) != hipSuccess) return e;
+            if ((e = dev_alloc(c, &H.cglob, std::max<size_t>(64, cols))) != hipSuccess) return e;
+        }
+        LP = AmgLevelPlan();  // host copy no longer needed
+    }
+    if ((e = dev_alloc(c, &H.x0, (size_t)n_loc0)) != hipSuccess) return e;
+    return hipMemset(H.x0, 0, (size_t)n_loc0 * sizeof(double));
+}
+}  // namespace shk
+
 extern "C" {
 
 const char* shk_last_error(void) { return g_err.c_str(); }
@@ -193,44 +238,13 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
     if ((e = hipHostMalloc((void**)&c->h_state, 2 * sizeof(KrylovState))) != hipSuccess) return bail(e, "pinned");
     if ((e = hipHostMalloc((void**)&c->h_part, kMaxParts * sizeof(double))) != hipSuccess) return bail(e, "pinned");
     if ((e = prepare_kernels(c)) != hipSuccess) return bail(e, "hipFuncSetAttribute(dynamic LDS)");
-    // multigrid hierarchy
+    // multigrid hierarchy of the owned diagonal block
     if (!c->plan.amg.empty()) {
-        const size_t nx = c->plan.amg.size();
-        c->amg_xf.resize(nx);
-        c->amg_lv.resize(nx);  // [0] unused; [l] for 1 <= l < nx
-        for (size_t l = 0; l < nx; ++l) {
-            AmgLevelPlan& LP = c->plan.amg[l];
-            AmgXfer& X = c->amg_xf[l];
-            X.n_fine = LP.n_fine; X.n_coarse = LP.n_coarse; X.dense = LP.dense;
-            if ((e = upload(c, &X.agg, LP.agg)) != hipSuccess) return bail(e, "amg upload");
-            if ((e = upload(c, &X.members, LP.members)) != hipSuccess) return bail(e, "amg upload");
-            if ((e = upload(c, &X.gptr, LP.gptr)) != hipSuccess) return bail(e, "amg upload");
-            if ((e = upload(c, &X.glist, LP.glist)) != hipSuccess) return bail(e, "amg upload");
-            if (!LP.dense) {
-                AmgLevel& L = c->amg_lv[l + 1 < nx ? l + 1 : l];
-                if (l + 1 >= nx) return bail(hipErrorUnknown, "amg plan ends on a sparse level");
-                L.n = LP.Ac.n_rows; L.nslice = LP.Ac.nslice; L.slots = LP.Ac.slots;
-                if ((e = upload(c, &L.ptr, LP.Ac.ptr)) != hipSuccess) return bail(e, "amg upload");
-                if ((e = upload(c, &L.col, LP.Ac.col)) != hipSuccess) return bail(e, "amg upload");
-                if ((e = upload(c, &L.rowlen, LP.Ac.rowlen)) != hipSuccess) return bail(e, "amg upload");
-                if ((e = upload(c, &L.diag_slot, LP.diag_slot)) != hipSuccess) return bail(e, "amg upload");
-                const size_t nr = (size_t)L.nslice * kSlice;
-                if ((e = dev_alloc(c, &L.vals, (size_t)L.slots)) != hipSuccess) return bail(e, "amg alloc");
-                double** vs[] = {&L.dinv, &L.x, &L.x2, &L.r};
-                for (double** v : vs) {
-                    if ((e = dev_alloc(c, v, nr)) != hipSuccess) return bail(e, "amg alloc");
-                    if ((e = hipMemset(*v, 0, nr * sizeof(double))) != hipSuccess) return bail(e, "memset");
-                }
-            } else {
-                const size_t nc = (size_t)LP.n_coarse;
-                if ((e = dev_alloc(c, &c->d_cdense, nc * nc)) != hipSuccess) return bail(e, "amg alloc");
-                if ((e = dev_alloc(c, &c->d_cinv, nc * nc)) != hipSuccess) return bail(e, "amg alloc");
-                if ((e = dev_alloc(c, &c->d_cr, 64)) != hipSuccess) return bail(e, "amg alloc");
-                if ((e = dev_alloc(c, &c->d_cx, 64)) != hipSuccess) return bail(e, "amg alloc");
-            }
-            LP = AmgLevelPlan();  // host copy no longer needed
-        }
-        double** vs[] = {&c->d_amg_x0, &c->d_phat, &c->d_shat};
+        if ((e = amg_upload(c, c->plan.amg, c->amg_local, c->n_loc)) != hipSuccess) return bail(e, "amg upload");
+        c->plan.amg = std::vector<AmgLevelPlan>();
+    }
+    {
+        double** vs[] = {&c->d_phat, &c->d_shat};
         for (double** v : vs) {
             if ((e = dev_alloc(c, v, nl)) != hipSuccess) return bail(e, "amg alloc");
             if ((e = hipMemset(*v, 0, nl * sizeof(double))) != hipSuccess) return bail(e, "memset");
@@ -269,11 +283,25 @@ int shk_set_params(shk_ctx* ctx, const shk_params* p) {
     if (!(p->g > 0 && p->rho_i > 0 && p->rho_w > 0 && p->nu > 0 && p->Lh > 0)) return fail("non-positive constant");
     if (p->newton_max_it < 0 || p->krylov_max_it < 1 || p->krylov_check_every < 0) return fail("bad iteration limits");
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
-    if (p->precond != SHK_PC_JACOBI && p->precond != SHK_PC_AMG) return fail("unknown preconditioner id");
-    if (p->precond == SHK_PC_AMG && c->amg_xf.empty())
-        return fail("multigrid hierarchy unavailable for this context (mesh of <= 64 vertices, or SHK_AMG=0)");
+    if (p->precond != SHK_PC_JACOBI && p->precond != SHK_PC_AMG && p->precond != SHK_PC_AMG_LOCAL)
+        return fail("unknown preconditioner id");
+    AmgHierarchy* H = nullptr;
+    if (p->precond == SHK_PC_AMG_LOCAL || (p->precond == SHK_PC_AMG && c->comm.nranks <= 1)) {
+        H = &c->amg_local;
+        if (!H->ready())
+            return fail("multigrid hierarchy unavailable for this context (mesh of <= 64 vertices, or SHK_AMG=0)");
+    } else if (p->precond == SHK_PC_AMG) {
+        // distributed hierarchy: built on first use, COLLECTIVELY (every subdomain must make this call)
+        H = &c->amg_dist;
+        if (!H->ready()) {
+            HIPCHK(hipSetDevice(c->device));
+            std::string err;
+            if (amg_setup_distributed(c, err)) return fail("distributed multigrid setup: " + err);
+        }
+    }
     c->params = *p;
-    c->use_amg = p->precond == SHK_PC_AMG;
+    c->use_amg = H != nullptr;
+    c->amg = H;
     derive_params(c);
     c->assembled = false;
     return 0;
@@ -454,11 +482,7 @@ static int read_aux_norm(Ctx* c, double* out) {  // fixed-order host sum of the 
 // residual, and the correction equation is solved again if the target was missed.
 static int krylov_solve(Ctx* c, int* its, int* converged, double* relres) {
     if (c->use_amg) {
-        // subdomain contexts precondition with the multigrid of their own diagonal block (additive Schwarz
-        // without overlap): ghost columns drop out of the smoother through a zero D^-1
-        if (c->n_loc > c->n_own)
-            HIPCHK(hipMemsetAsync(c->d_dinv + c->n_own, 0, (size_t)(c->n_loc - c->n_own) * sizeof(double), c->stream));
-        amg_numeric_setup(c);   // Galerkin coarse operators of the Jacobian just assembled
+        HIPCHK(amg_numeric_setup(c));   // Galerkin coarse operators of the Jacobian just assembled
     } else {
         HIPCHK(halo_exchange(c, c->d_dinv));  // ghost columns of A' = A D^-1 need their owners' diagonal
         launch_scale(c);
@@ -590,40 +614,46 @@ int shk_set_halo(shk_ctx* ctx, int32_t n_nbr, const int32_t* nbr_rank, const int
     CHECK_CTX(ctx);
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (n_nbr < 0 || (n_nbr > 0 && (!nbr_rank || !send_ptr || !recv_ptr))) return fail("bad halo plan");
+    if (!c->comm.plans.empty()) return fail("halo plan already installed");
     HIPCHK(hipSetDevice(c->device));
     Comm& m = c->comm;
-    m.nbr.assign(nbr_rank, nbr_rank + n_nbr);
-    m.send_ptr.assign(1, 0);
-    m.recv_ptr.assign(1, 0);
+    HaloPlan P;
+    P.n_own = c->n_own;
+    P.nbr.assign(nbr_rank, nbr_rank + n_nbr);
+    P.send_ptr.assign(1, 0);
+    P.recv_ptr.assign(1, 0);
     if (n_nbr > 0) {
-        m.send_ptr.assign(send_ptr, send_ptr + n_nbr + 1);
-        m.recv_ptr.assign(recv_ptr, recv_ptr + n_nbr + 1);
+        P.send_ptr.assign(send_ptr, send_ptr + n_nbr + 1);
+        P.recv_ptr.assign(recv_ptr, recv_ptr + n_nbr + 1);
     }
     for (int k = 0; k < n_nbr; ++k)
-        if (m.send_ptr[k + 1] < m.send_ptr[k] || m.recv_ptr[k + 1] < m.recv_ptr[k] || (k > 0 && m.nbr[k] <= m.nbr[k - 1]))
+        if (P.send_ptr[k + 1] < P.send_ptr[k] || P.recv_ptr[k + 1] < P.recv_ptr[k] || (k > 0 && P.nbr[k] <= P.nbr[k - 1]))
             return fail("halo plan: offsets must be non-decreasing and neighbour ranks ascending");
-    const int64_t nsend = m.send_ptr.back(), nrecv = m.recv_ptr.back();
-    if (m.send_ptr[0] != 0 || m.recv_ptr[0] != 0) return fail("halo plan: offsets must start at 0");
+    const int64_t nsend = P.send_ptr.back(), nrecv = P.recv_ptr.back();
+    if (P.send_ptr[0] != 0 || P.recv_ptr[0] != 0) return fail("halo plan: offsets must start at 0");
     if (nrecv != c->n_loc - c->n_own) return fail("halo plan: receive counts do not cover the ghost vertices");
     if (nsend > 0 && !send_idx) return fail("halo plan: null send list");
-    std::vector<int32_t> idx((size_t)nsend);
+    P.h_send_idx.resize((size_t)nsend);
     for (int64_t i = 0; i < nsend; ++i) {
         if (send_idx[i] < 0 || send_idx[i] >= c->n_own) return fail("halo plan: send index is not an owned vertex");
-        idx[i] = c->plan.iperm[send_idx[i]];
+        P.h_send_idx[i] = c->plan.iperm[send_idx[i]];
     }
-    hipError_t e;
-    if ((e = dev_alloc(c, &m.d_send_idx, (size_t)nsend)) != hipSuccess) return fail("halo alloc");
-    if ((e = dev_alloc(c, &m.d_sendbuf, (size_t)nsend)) != hipSuccess) return fail("halo alloc");
-    if (nsend > 0) HIPCHK(hipMemcpy(m.d_send_idx, idx.data(), (size_t)nsend * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (dev_alloc(c, &P.d_send_idx, (size_t)nsend) != hipSuccess) return fail("halo alloc");
+    if (dev_alloc(c, &m.d_sendbuf, (size_t)nsend) != hipSuccess) return fail("halo alloc");
+    if (nsend > 0)
+        HIPCHK(hipMemcpy(P.d_send_idx, P.h_send_idx.data(), (size_t)nsend * sizeof(int32_t), hipMemcpyHostToDevice));
     HIPCHK(hipHostMalloc((void**)&m.h_send, std::max<size_t>(1, (size_t)nsend) * sizeof(double)));
     HIPCHK(hipHostMalloc((void**)&m.h_recv, std::max<size_t>(1, (size_t)nrecv) * sizeof(double)));
-    HIPCHK(hipHostMalloc((void**)&m.h_red, (size_t)P_COUNT * kMaxParts * sizeof(double)));
+    m.h_red_cap = (size_t)P_COUNT * kMaxParts;
+    HIPCHK(hipHostMalloc((void**)&m.h_red, m.h_red_cap * sizeof(double)));
+    m.plans.push_back(std::move(P));
     return 0;
 }
 
 static int comm_common(Ctx* c, int rank, int nranks) {
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail("bad rank / nranks");
-    for (int r : c->comm.nbr)
+    if (c->comm.plans.empty()) return fail("call shk_set_halo before initialising the communicator");
+    for (int r : c->comm.plans[0].nbr)
         if (r < 0 || r >= nranks || r == rank) return fail("halo plan names a neighbour outside the communicator");
     if (nranks > 1 && c->d_red == c->d_part) {
         double* red = nullptr;
@@ -662,7 +692,6 @@ int shk_comm_init_callbacks(shk_ctx* ctx, int32_t rank, int32_t nranks, shk_exch
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!exchange || !allreduce) return fail("null callback");
     if (c->comm.kind != Comm::NONE) return fail("communicator already initialised");
-    if (!c->comm.h_red) return fail("call shk_set_halo before initialising the communicator");
     if (comm_common(c, rank, nranks)) return -1;
     c->comm.cb_exchange = exchange;
     c->comm.cb_allreduce = allreduce;

@@ -91,24 +91,24 @@ __global__ __launch_bounds__(kBlock) void k_pack(int64_t n, const int32_t* __res
         buf[i] = v[idx[i]];
 }
 
-// Fill the ghost segment [n_own, n_loc) of `vec` with the owners' current values.
-hipError_t halo_exchange(Ctx* c, double* vec) {
+// Fill the ghost segment of `vec` (a vector of the level that `P` belongs to) with the owners' current values.
+hipError_t halo_exchange_plan(Ctx* c, const HaloPlan& P, double* vec) {
     Comm& m = c->comm;
-    if (m.kind == Comm::NONE || m.nranks <= 1 || m.nbr.empty()) return hipSuccess;
+    if (m.kind == Comm::NONE || m.nranks <= 1 || P.nbr.empty()) return hipSuccess;
     PhaseTimer t(c, SHK_PH_HALO);
-    const int64_t nsend = m.send_ptr.back(), nrecv = m.recv_ptr.back();
+    const int64_t nsend = P.send_ptr.back(), nrecv = P.recv_ptr.back();
     if (nsend > 0) {
         const int g = (int)std::min<int64_t>((nsend + kBlock - 1) / kBlock, 1024);
-        hipLaunchKernelGGL(k_pack, dim3(g), dim3(kBlock), 0, c->stream, nsend, m.d_send_idx, vec, m.d_sendbuf);
+        hipLaunchKernelGGL(k_pack, dim3(g), dim3(kBlock), 0, c->stream, nsend, P.d_send_idx, vec, m.d_sendbuf);
     }
-    double* ghost = vec + c->n_own;
+    double* ghost = vec + P.n_own;
     if (m.kind == Comm::RCCL) {
         ncclComm_t comm = reinterpret_cast<ncclComm_t>(m.nccl);
         g_rccl.GroupStart();
-        for (size_t k = 0; k < m.nbr.size(); ++k) {
-            const int64_t ns = m.send_ptr[k + 1] - m.send_ptr[k], nr = m.recv_ptr[k + 1] - m.recv_ptr[k];
-            if (ns > 0) g_rccl.Send(m.d_sendbuf + m.send_ptr[k], (size_t)ns, ncclDouble, m.nbr[k], comm, c->stream);
-            if (nr > 0) g_rccl.Recv(ghost + m.recv_ptr[k], (size_t)nr, ncclDouble, m.nbr[k], comm, c->stream);
+        for (size_t k = 0; k < P.nbr.size(); ++k) {
+            const int64_t ns = P.send_ptr[k + 1] - P.send_ptr[k], nr = P.recv_ptr[k + 1] - P.recv_ptr[k];
+            if (ns > 0) g_rccl.Send(m.d_sendbuf + P.send_ptr[k], (size_t)ns, ncclDouble, P.nbr[k], comm, c->stream);
+            if (nr > 0) g_rccl.Recv(ghost + P.recv_ptr[k], (size_t)nr, ncclDouble, P.nbr[k], comm, c->stream);
         }
         ncclResult_t r = g_rccl.GroupEnd();
         return r == ncclSuccess ? hipSuccess : hipErrorUnknown;
@@ -119,30 +119,52 @@ hipError_t halo_exchange(Ctx* c, double* vec) {
         e = hipMemcpyAsync(m.h_send, m.d_sendbuf, (size_t)nsend * sizeof(double), hipMemcpyDeviceToHost, c->stream);
     if (e != hipSuccess) return e;
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return e;
-    if (m.cb_exchange(m.cb_user, m.h_send, m.h_recv) != 0) return hipErrorUnknown;
+    std::vector<int32_t> nb(P.nbr.begin(), P.nbr.end());
+    if (m.cb_exchange(m.cb_user, (int32_t)nb.size(), nb.data(), m.h_send, P.send_ptr.data(), m.h_recv,
+                      P.recv_ptr.data()) != 0)
+        return hipErrorUnknown;
     if (nrecv > 0)
         e = hipMemcpyAsync(ghost, m.h_recv, (size_t)nrecv * sizeof(double), hipMemcpyHostToDevice, c->stream);
     return e;
 }
 
-// Element-wise sum over subdomains of `nslots` consecutive partial arrays starting at slot `first`.
-hipError_t allreduce_parts(Ctx* c, int first, int nslots) {
+hipError_t halo_exchange(Ctx* c, double* vec) {
+    if (c->comm.plans.empty()) return hipSuccess;
+    return halo_exchange_plan(c, c->comm.plans[0], vec);
+}
+
+// dst = element-wise sum over subdomains of src (n doubles, device memory; src == dst allowed).
+hipError_t allreduce_buffer(Ctx* c, const double* src, double* dst, size_t n) {
     Comm& m = c->comm;
-    if (m.kind == Comm::NONE || m.nranks <= 1) return hipSuccess;
+    if (m.kind == Comm::NONE || m.nranks <= 1) {
+        if (src != dst) return hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
+        return hipSuccess;
+    }
     PhaseTimer t(c, SHK_PH_HALO);
-    // out of place: the local partials (d_part) keep zeros beyond this rank's grid, the sums go to d_red
-    const double* src = c->d_part + (size_t)first * kMaxParts;
-    double* dst = c->d_red + (size_t)first * kMaxParts;
-    const size_t n = (size_t)nslots * kMaxParts;
     if (m.kind == Comm::RCCL) {
         ncclResult_t r = g_rccl.AllReduce(src, dst, n, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(m.nccl), c->stream);
         return r == ncclSuccess ? hipSuccess : hipErrorUnknown;
+    }
+    if (n > m.h_red_cap) {
+        if (m.h_red) (void)hipHostFree(m.h_red);
+        m.h_red = nullptr;
+        hipError_t e = hipHostMalloc((void**)&m.h_red, n * sizeof(double));
+        if (e != hipSuccess) return e;
+        m.h_red_cap = n;
     }
     hipError_t e = hipMemcpyAsync(m.h_red, src, n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
     if (e != hipSuccess) return e;
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return e;
     if (m.cb_allreduce(m.cb_user, m.h_red, (int64_t)n) != 0) return hipErrorUnknown;
     return hipMemcpyAsync(dst, m.h_red, n * sizeof(double), hipMemcpyHostToDevice, c->stream);
+}
+
+// Element-wise sum over subdomains of `nslots` consecutive partial arrays starting at slot `first`
+// (out of place: the local partials keep zeros beyond this rank's grid, the sums go to d_red).
+hipError_t allreduce_parts(Ctx* c, int first, int nslots) {
+    if (c->comm.kind == Comm::NONE || c->comm.nranks <= 1) return hipSuccess;
+    return allreduce_buffer(c, c->d_part + (size_t)first * kMaxParts, c->d_red + (size_t)first * kMaxParts,
+                            (size_t)nslots * kMaxParts);
 }
 
 }  // namespace shk

@@ -86,16 +86,38 @@ inline int32_t sell_fits_cache(int64_t slots) { return slots * 12 < (int64_t)192
 
 // Multigrid hierarchy on the device (shk_amg.hip).  Level 0 is the Jacobian itself (Ctx::d_vals, d_dinv).
 struct AmgLevel {
-    int32_t n = 0, nslice = 0;
+    int32_t n = 0, n_cols = 0, nslice = 0;
     int64_t slots = 0;
     int32_t *ptr = nullptr, *col = nullptr, *diag_slot = nullptr;
     uint8_t* rowlen = nullptr;
     double *vals = nullptr, *dinv = nullptr, *x = nullptr, *x2 = nullptr, *r = nullptr;
 };
 struct AmgXfer {  // level l -> l+1
-    int32_t n_fine = 0, n_coarse = 0;
+    int32_t n_fine = 0, n_coarse = 0, n_coarse_cols = 0;
     int32_t *agg = nullptr, *members = nullptr, *gptr = nullptr, *glist = nullptr;
     bool dense = false;
+};
+// A hierarchy is either block-local (the owned diagonal block of a subdomain, or the whole matrix of a single
+// context: no communication) or distributed (ghost columns kept on every level, per-level halo plans, one
+// dense coarsest operator shared by all subdomains).
+struct AmgHierarchy {
+    std::vector<AmgLevel> lv;    // [0] unused, [l] = sparse coarse level l
+    std::vector<AmgXfer> xf;     // [l] : level l -> l+1; the last one lands on the dense coarsest level
+    std::vector<int> plan_of;    // distributed: index into Comm::plans of level l's halo plan (size = xf.size())
+    bool distributed = false;
+    int halo_levels = 1 << 30;   // levels [0, halo_levels) exchange ghosts inside the smoother
+    int32_t n_glob = 0, offset = 0;  // dense coarsest operator: n_glob x n_glob, my rows start at `offset`
+    double *x0 = nullptr, *cdense = nullptr, *cinv = nullptr, *cr = nullptr, *cx = nullptr, *cglob = nullptr;
+    bool ready() const { return !xf.empty(); }
+};
+
+// Ghost-exchange plan of one level of a subdomain (level 0 = the mesh, l >= 1 = multigrid levels).
+struct HaloPlan {
+    int64_t n_own = 0;                        // the ghost segment of this level's vectors starts here
+    std::vector<int> nbr;                     // neighbour ranks, ascending
+    std::vector<int64_t> send_ptr, recv_ptr;  // per-neighbour offsets into the packed buffers (size nbr+1)
+    std::vector<int32_t> h_send_idx;          // owned rows to send (internal numbering), host copy
+    int32_t* d_send_idx = nullptr;
 };
 
 // Communication state of a subdomain context (shk_comm.hip).
@@ -106,11 +128,10 @@ struct Comm {
     shk_exchange_fn cb_exchange = nullptr;   // CALLBACK transport
     shk_allreduce_fn cb_allreduce = nullptr;
     void* cb_user = nullptr;
-    std::vector<int> nbr;                    // neighbour ranks, ascending
-    std::vector<int64_t> send_ptr, recv_ptr; // per-neighbour offsets into the packed buffers
-    int32_t* d_send_idx = nullptr;           // internal ids of the owned vertices to send
-    double* d_sendbuf = nullptr;
+    std::vector<HaloPlan> plans;             // [0] fine level, [l] multigrid level l (distributed hierarchy)
+    double* d_sendbuf = nullptr;             // sized for plans[0], the largest
     double *h_send = nullptr, *h_recv = nullptr, *h_red = nullptr;  // pinned staging (CALLBACK)
+    size_t h_red_cap = 0;
 };
 
 struct Ctx {
@@ -149,10 +170,9 @@ struct Ctx {
            *d_y = nullptr, *d_ytot = nullptr, *d_rhs = nullptr;
     double cur_rtol2 = 0.0, cur_atol2 = 0.0;   // stopping rule of the inner solve being enqueued
     // multigrid preconditioner (empty when unavailable: subdomain contexts, tiny meshes)
-    std::vector<AmgLevel> amg_lv;   // [0] unused, [l] = sparse coarse level l
-    std::vector<AmgXfer> amg_xf;    // [l] : level l -> l+1, the last one lands on the dense coarsest level
-    double *d_amg_x0 = nullptr, *d_phat = nullptr, *d_shat = nullptr;
-    double *d_cdense = nullptr, *d_cinv = nullptr, *d_cr = nullptr, *d_cx = nullptr;
+    AmgHierarchy amg_local, amg_dist;
+    AmgHierarchy* amg = nullptr;    // the active one when use_amg
+    double *d_phat = nullptr, *d_shat = nullptr;
     bool use_amg = false;
     double* d_part = nullptr;  // 8 arrays of kMaxParts: this subdomain's partial sums
     double* d_red = nullptr;   // the same summed over subdomains (== d_part for a single context)
@@ -220,9 +240,14 @@ const char* rccl_load();
 int rccl_unique_id(void* out128);
 const char* rccl_init(Ctx* c, int rank, int nranks, const void* id128);
 void comm_destroy(Ctx* c);
-hipError_t halo_exchange(Ctx* c, double* vec);
-void amg_numeric_setup(Ctx* c);
-void amg_vcycle(Ctx* c, const double* rin, double* zout);
+hipError_t halo_exchange(Ctx* c, double* vec);                       // level 0
+hipError_t halo_exchange_plan(Ctx* c, const HaloPlan& P, double* vec);
+hipError_t allreduce_buffer(Ctx* c, const double* src, double* dst, size_t n);  // element-wise sum over subdomains
+int amg_setup_distributed(Ctx* c, std::string& err);  // collective
+hipError_t amg_numeric_setup(Ctx* c);
+hipError_t amg_vcycle(Ctx* c, const double* rin, double* zout);
+// upload one host hierarchy (shk_api.hip: owns the allocation helpers)
+hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H, int64_t n_loc0);
 hipError_t allreduce_parts(Ctx* c, int first, int nslots);
 
 struct PhaseTimer {  // RAII hipEvent pair when profiling is on

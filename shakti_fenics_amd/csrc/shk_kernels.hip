@@ -552,7 +552,7 @@ hipError_t krylov_iteration(Ctx* c, int it) {
     const double* A = c->use_amg ? c->d_vals : c->d_vals_s;
     double* phat = c->use_amg ? c->d_phat : c->d_p;
     double* shat = c->use_amg ? c->d_shat : c->d_s;
-    if (c->use_amg) amg_vcycle(c, c->d_p, phat);
+    if (c->use_amg && (e = amg_vcycle(c, c->d_p, phat)) != hipSuccess) return e;
     if ((e = halo_exchange(c, phat)) != hipSuccess) return e;
     {
         PhaseTimer t(c, SHK_PH_SPMV);
@@ -564,7 +564,7 @@ hipError_t krylov_iteration(Ctx* c, int it) {
         hipLaunchKernelGGL(k_bicg_s, g, b, 0, c->stream, c->n_own, it, c->params.krylov_max_it, c->cur_rtol2,
                            c->cur_atol2, c->np, c->d_red, part, c->d_r, c->d_v, c->d_rhat, c->d_s, c->d_state);
     }
-    if (c->use_amg) amg_vcycle(c, c->d_s, shat);
+    if (c->use_amg && (e = amg_vcycle(c, c->d_s, shat)) != hipSuccess) return e;
     if ((e = halo_exchange(c, shat)) != hipSuccess) return e;
     {
         PhaseTimer t(c, SHK_PH_SPMV);

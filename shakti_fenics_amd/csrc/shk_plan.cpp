@@ -246,11 +246,17 @@ std::string build_plan(int64_t n_own, int64_t n_loc, int64_t ne, const double* x
 }
 
 // ---- aggregation multigrid hierarchy (static patterns) ----
-static std::string coarsen(const SellPattern& Af, const std::vector<int32_t>& agg, int32_t n_coarse, bool dense,
-                           AmgLevelPlan& L) {
+// One coarsening step.  `agg` maps the fine rows to coarse rows; `colmap` maps EVERY fine column (owned
+// and ghost) to a coarse column, or -1 to drop it (ghost couplings of a block-local hierarchy).  Sparse result:
+// coarse columns are local ids (owned rows first, then coarse ghosts); dense result: `n_coarse_cols` columns
+// (global ids when the coarsest operator is shared by all subdomains), row-major targets I * n_coarse_cols + J.
+std::string coarsen(const SellPattern& Af, const std::vector<int32_t>& agg, const std::vector<int32_t>& colmap,
+                    int32_t n_coarse, int32_t n_coarse_cols, bool dense, AmgLevelPlan& L) {
     const int32_t nf = Af.n_rows;
+    if ((int32_t)agg.size() != nf || (int32_t)colmap.size() != Af.n_cols) return "coarsen: map sizes";
     L.n_fine = nf;
     L.n_coarse = n_coarse;
+    L.n_coarse_cols = n_coarse_cols;
     L.agg = agg;
     L.dense = dense;
     L.members.assign((size_t)4 * n_coarse, -1);
@@ -258,6 +264,7 @@ static std::string coarsen(const SellPattern& Af, const std::vector<int32_t>& ag
         std::vector<uint8_t> cnt(n_coarse, 0);
         for (int32_t i = 0; i < nf; ++i) {
             const int32_t I = agg[i];
+            if (I < 0 || I >= n_coarse) return "aggregate id out of range";
             if (cnt[I] >= 4) return "aggregate with more than 4 members";
             L.members[(size_t)4 * I + cnt[I]++] = i;
         }
@@ -268,44 +275,45 @@ static std::string coarsen(const SellPattern& Af, const std::vector<int32_t>& ag
                 if (L.members[(size_t)4 * I + m] / 256 != g0) return "aggregate straddles a 256-row group";
         }
     }
-    // coarse rows: sorted unique aggregates of the members' columns, diagonal first
-    std::vector<int32_t> rp(n_coarse + 1, 0), ci;
-    std::vector<int32_t> tmp;
-    ci.reserve((size_t)Af.nnz / 2);
-    for (int32_t I = 0; I < n_coarse; ++I) {
-        tmp.clear();
-        for (int m = 0; m < 4; ++m) {
-            const int32_t i = L.members[(size_t)4 * I + m];
-            if (i < 0) continue;
-            const int32_t s = i / kSlice, l = i % kSlice, base = Af.ptr[s];
-            for (int k = 0; k < Af.rowlen[i]; ++k) {
-                const int32_t cj = Af.col[base + k * kSlice + l];
-                if (cj < nf) tmp.push_back(agg[cj]);  // ghost columns couple to other subdomains: left out
-            }
-        }
-        std::sort(tmp.begin(), tmp.end());
-        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-        auto it = std::lower_bound(tmp.begin(), tmp.end(), I);
-        std::rotate(tmp.begin(), it, it + 1);
-        if (tmp.size() > 255) return "coarse row longer than 255";
-        ci.insert(ci.end(), tmp.begin(), tmp.end());
-        rp[I + 1] = (int32_t)ci.size();
-    }
     std::vector<int32_t> target((size_t)Af.slots, -1);  // coarse slot of every fine slot
     int64_t nslots_c;
     if (dense) {
-        nslots_c = (int64_t)n_coarse * n_coarse;
+        nslots_c = (int64_t)n_coarse * n_coarse_cols;
         for (int32_t i = 0; i < nf; ++i) {
             const int32_t s = i / kSlice, l = i % kSlice, base = Af.ptr[s], I = agg[i];
             for (int k = 0; k < Af.rowlen[i]; ++k) {
                 const int32_t slot = base + k * kSlice + l;
-                if (Af.col[slot] < nf) target[slot] = I * n_coarse + agg[Af.col[slot]];
+                const int32_t J = colmap[Af.col[slot]];
+                if (J >= 0) target[slot] = I * n_coarse_cols + J;
             }
         }
     } else {
+        // coarse rows: sorted unique coarse columns of the members' entries, diagonal first
+        std::vector<int32_t> rp(n_coarse + 1, 0), ci, tmp;
+        ci.reserve((size_t)Af.nnz / 2);
+        for (int32_t I = 0; I < n_coarse; ++I) {
+            tmp.clear();
+            for (int m = 0; m < 4; ++m) {
+                const int32_t i = L.members[(size_t)4 * I + m];
+                if (i < 0) continue;
+                const int32_t s = i / kSlice, l = i % kSlice, base = Af.ptr[s];
+                for (int k = 0; k < Af.rowlen[i]; ++k) {
+                    const int32_t J = colmap[Af.col[base + k * kSlice + l]];
+                    if (J >= 0) tmp.push_back(J);
+                }
+            }
+            std::sort(tmp.begin(), tmp.end());
+            tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+            auto it = std::lower_bound(tmp.begin(), tmp.end(), I);
+            if (it == tmp.end() || *it != I) return "coarse row without a diagonal";
+            std::rotate(tmp.begin(), it, it + 1);
+            if (tmp.size() > 255) return "coarse row longer than 255";
+            ci.insert(ci.end(), tmp.begin(), tmp.end());
+            rp[I + 1] = (int32_t)ci.size();
+        }
         SellPattern& C = L.Ac;
         C.n_rows = n_coarse;
-        C.n_cols = n_coarse;
+        C.n_cols = n_coarse_cols;
         C.nslice = (n_coarse + kSlice - 1) / kSlice;
         C.rowlen.assign((size_t)C.nslice * kSlice, 0);
         C.ptr.assign(C.nslice + 1, 0);
@@ -331,11 +339,6 @@ static std::string coarsen(const SellPattern& Af, const std::vector<int32_t>& ag
                 C.col[base + k * kSlice + l] = (k < C.rowlen[I]) ? ci[rp[I] + k] : I;
             L.diag_slot[I] = base + l;
         }
-        for (int32_t s = C.n_rows; s < C.nslice * kSlice; ++s) {  // tail padding rows point at column 0
-            const int32_t sl = s / kSlice, l = s % kSlice, base = C.ptr[sl];
-            const int w = (C.ptr[sl + 1] - base) / kSlice;
-            for (int k = 0; k < w; ++k) C.col[base + k * kSlice + l] = 0;
-        }
         nslots_c = slots;
         for (int32_t i = 0; i < nf; ++i) {
             const int32_t s = i / kSlice, l = i % kSlice, base = Af.ptr[s], I = agg[i];
@@ -344,8 +347,8 @@ static std::string coarsen(const SellPattern& Af, const std::vector<int32_t>& ag
             const int len = rp[I + 1] - rp[I];
             for (int k = 0; k < Af.rowlen[i]; ++k) {
                 const int32_t slot = base + k * kSlice + l;
-                if (Af.col[slot] >= nf) continue;
-                const int32_t J = agg[Af.col[slot]];
+                const int32_t J = colmap[Af.col[slot]];
+                if (J < 0) continue;
                 int kk = 0;
                 while (kk < len && row[kk] != J) ++kk;
                 target[slot] = cbase + kk * kSlice + cl;
@@ -364,17 +367,20 @@ static std::string coarsen(const SellPattern& Af, const std::vector<int32_t>& ag
     return std::string();
 }
 
+// Block-local hierarchy of the owned diagonal block (ghost columns dropped): needs no communication.
 std::string build_amg(HostPlan& P, const PlanOptions& opt) {
     P.amg.clear();
     P.amg.reserve(40);  // `Af` below points into this vector: no reallocation (4^40 rows is out of reach)
     const int coarsest = std::min(64, std::max(4, opt.amg_coarsest));
     const SellPattern* Af = &P.A;
-    std::vector<int32_t> agg(P.n_own);
+    std::vector<int32_t> agg(P.n_own), colmap;
     for (int64_t i = 0; i < P.n_own; ++i) agg[i] = P.krank[i] / 4;
     while (Af->n_rows > coarsest) {
         const int32_t nc = (Af->n_rows + 3) / 4;
         P.amg.emplace_back();
-        std::string err = coarsen(*Af, agg, nc, nc <= coarsest, P.amg.back());
+        colmap.assign(Af->n_cols, -1);
+        std::copy(agg.begin(), agg.end(), colmap.begin());
+        std::string err = coarsen(*Af, agg, colmap, nc, nc, nc <= coarsest, P.amg.back());
         if (!err.empty()) { P.amg.clear(); return "amg: " + err; }
         if (P.amg.back().dense) break;
         Af = &P.amg.back().Ac;

@@ -41,7 +41,7 @@ struct SellPattern {
 // (consecutive leaves of the k-d order), piecewise-constant prolongation, Galerkin coarse operator
 // A_c = P^T A P whose sparsity never changes, so its values are a fixed gather-sum of the finer values.
 struct AmgLevelPlan {
-    int32_t n_fine = 0, n_coarse = 0;
+    int32_t n_fine = 0, n_coarse = 0, n_coarse_cols = 0;
     std::vector<int32_t> agg;       // n_fine          : aggregate (= coarse row) of each fine row
     std::vector<int32_t> members;   // 4*n_coarse      : fine rows of each aggregate, -1 padded; all inside one
                                     //                   256-row group of the fine level
@@ -78,6 +78,8 @@ std::string build_plan(int64_t n_own, int64_t n_loc, int64_t ne, const double* x
                        const PlanOptions& opt, HostPlan& out);
 
 std::string build_amg(HostPlan& P, const PlanOptions& opt);
+std::string coarsen(const SellPattern& Af, const std::vector<int32_t>& agg, const std::vector<int32_t>& colmap,
+                    int32_t n_coarse, int32_t n_coarse_cols, bool dense, AmgLevelPlan& L);
 
 // External CSR (rows = external owned ids, columns external local ids ascending) of a SELL pattern.
 void sell_to_csr(const HostPlan& P, const double* sell_vals, std::vector<int32_t>& rowptr,

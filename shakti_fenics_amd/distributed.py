@@ -12,23 +12,21 @@ from . import _lib
 from .partition import Subdomain
 
 
-def gloo_callbacks(sub: Subdomain, group=None):
+def gloo_callbacks(group=None):
     """(exchange, allreduce) callables for ShaktiHip.comm_init_callbacks over a torch.distributed group."""
     import torch
     import torch.distributed as dist
 
-    nbr = [int(r) for r in sub.nbr]
-    sp, rp = sub.send_ptr, sub.recv_ptr
-
-    def exchange(send: np.ndarray, recv: np.ndarray):
-        reqs = []
-        rbufs = []
+    def exchange(nbr, send, sp, recv, rp):
+        reqs, rbufs = [], []
         for k, r in enumerate(nbr):
             t = torch.empty(int(rp[k + 1] - rp[k]), dtype=torch.float64)
             rbufs.append(t)
-            reqs.append(dist.irecv(t, src=r, group=group))
+            if t.numel():
+                reqs.append(dist.irecv(t, src=int(r), group=group))
         for k, r in enumerate(nbr):
-            reqs.append(dist.isend(torch.from_numpy(send[sp[k]:sp[k + 1]].copy()), dst=r, group=group))
+            if sp[k + 1] > sp[k]:
+                reqs.append(dist.isend(torch.from_numpy(send[sp[k]:sp[k + 1]].copy()), dst=int(r), group=group))
         for q in reqs:
             q.wait()
         for k in range(len(nbr)):
@@ -55,7 +53,7 @@ def make_context(sub: Subdomain, device: int, transport: str = "rccl", group=Non
         dist.broadcast_object_list(obj, src=0, group=group)
         ctx.comm_init_rccl(sub.rank, sub.nranks, obj[0])
     elif transport == "gloo":
-        ex, ar = gloo_callbacks(sub, group)
+        ex, ar = gloo_callbacks(group)
         ctx.comm_init_callbacks(sub.rank, sub.nranks, ex, ar)
     else:
         raise ValueError(f"unknown transport {transport!r}")

@@ -73,6 +73,10 @@ def main():
         report.update(errs=errs, ref_infos=ref_infos, ghost_mismatch=gerr)
         ok = (all(e < 1e-7 for e in errs.values()) and gerr == 0.0
               and [x[0] for x in infos] == [x[0] for x in ref_infos])
+        if a.precond == "amg":
+            # the distributed hierarchy keeps every cross-subdomain coupling (only the aggregates differ: they follow
+            # each subdomain's own k-d order), so Krylov iteration counts must stay at the one-subdomain level
+            ok = ok and all(x[1] <= 1.3 * y[1] + 3 for x, y in zip(infos, ref_infos))
         report["ok"] = ok
         print(json.dumps(report), flush=True)
         if a.out:

@@ -30,13 +30,13 @@ def main():
     dom, f, bc, g = make_case(nx=37, ny=19, Lx=20e3, Ly=10e3, perturb=True)
     prm = O.Params()
     sub = partition(dom, world, rank)
-    exchange, allreduce = gloo_callbacks(sub)
+    exchange, allreduce = gloo_callbacks()
     gid, no = sub.gid, sub.n_own
 
     def halo(vec):
         send = vec[sub.send_idx].copy()
         recv = np.empty(sub.n_ghost)
-        exchange(send, recv)
+        exchange(sub.nbr, send, sub.send_ptr, recv, sub.recv_ptr)
         vec[no:] = recv
 
     # (1) ghost exchange

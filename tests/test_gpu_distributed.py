@@ -24,9 +24,9 @@ def _launch(nproc, transport, port, extra=()):
     return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
 
 
-@pytest.mark.parametrize("nproc,precond", [(2, "jacobi"), (3, "jacobi"), (3, "amg")])
+@pytest.mark.parametrize("nproc,precond", [(2, "jacobi"), (3, "jacobi"), (3, "amg"), (2, "amg_local")])
 def test_partitioned_matches_single_gloo(nproc, precond):
-    r = _launch(nproc, "gloo", 29511 + nproc + (10 if precond == "amg" else 0), ("--precond", precond))
+    r = _launch(nproc, "gloo", 29511 + nproc + {"jacobi": 0, "amg": 10, "amg_local": 20}[precond], ("--precond", precond))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     rep = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert rep["ok"] and rep["ghost_mismatch"] == 0.0
