@@ -174,6 +174,87 @@ __global__ __launch_bounds__(kBlock) void k_amg_post(const AmgSmoothArgs a) {
     }
 }
 
+// ---- tail: every level with <= kTailRows rows runs inside ONE workgroup (restrictions, dense coarsest solve,
+// prolongations and smoothing sweeps separated by workgroup barriers) instead of ~4 tiny launches per level.
+constexpr int kTailRows = 4096;
+constexpr int kTailThreads = 1024;
+constexpr int kTailMaxLevels = 8;
+
+struct TailLevel {
+    int32_t n, nslice, n_coarse;         // rows, slices, rows of the next level
+    const int32_t *ptr, *col, *agg, *members;
+    const double *vals, *dinv;
+    double *x, *x2, *r;
+};
+struct TailArgs {
+    int nlev;
+    TailLevel lv[kTailMaxLevels];
+    int n_c, row0, ncols;                // dense coarsest: my rows, first row, columns
+    const double* inv;
+    double *cr, *cx;
+    const double* cglob;                 // distributed: gathered coarsest rhs (phase 2), else == cr
+    double omega;
+    const int* done;
+};
+
+__device__ __forceinline__ void tail_post(const TailLevel& L, const double* x, double* xo, double omega) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int s = wave; s < L.nslice; s += kTailThreads / 64) {
+        const int base = L.ptr[s];
+        const int width = (L.ptr[s + 1] - base) >> 6;
+        double sum = 0.0;
+        for (int k = 0; k < width; ++k) sum += L.vals[base + k * kSlice + lane] * x[L.col[base + k * kSlice + lane]];
+        const int row = s * kSlice + lane;
+        if (row < L.n) xo[row] = x[row] + omega * L.dinv[row] * (L.r[row] - sum);
+    }
+}
+
+// PHASE 0: whole tail (one context).  PHASE 1: restrictions only.  PHASE 2: coarsest solve + way up (the
+// gathered coarsest right-hand side was summed over subdomains between the two).
+template <int PHASE>
+__global__ __launch_bounds__(kTailThreads) void k_amg_tail(const TailArgs a) {
+    if (*a.done) return;
+    const int tid = threadIdx.x;
+    if (PHASE != 2) {
+        for (int k = 0; k < a.nlev; ++k) {
+            const TailLevel& L = a.lv[k];
+            double* rc = (k + 1 < a.nlev) ? a.lv[k + 1].r : a.cr;
+            for (int I = tid; I < L.n_coarse; I += kTailThreads) {
+                const int4 m = reinterpret_cast<const int4*>(L.members)[I];
+                double acc = L.r[m.x];
+                if (m.y >= 0) acc += L.r[m.y];
+                if (m.z >= 0) acc += L.r[m.z];
+                if (m.w >= 0) acc += L.r[m.w];
+                rc[I] = acc;
+            }
+            __syncthreads();
+        }
+    }
+    if (PHASE == 1) return;
+    {   // dense coarsest solve: one wave per row, lanes over columns
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int i = wave; i < a.n_c; i += kTailThreads / 64) {
+            const double* row = a.inv + (size_t)(a.row0 + i) * a.ncols;
+            double acc = 0.0;
+            for (int j = lane; j < a.ncols; j += 64) acc += row[j] * a.cglob[j];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+            if (lane == 0) a.cx[i] = acc;
+        }
+        __syncthreads();
+    }
+    for (int k = a.nlev - 1; k >= 0; --k) {
+        const TailLevel& L = a.lv[k];
+        const double* ec = (k + 1 < a.nlev) ? a.lv[k + 1].x2 : a.cx;
+        for (int i = tid; i < L.n; i += kTailThreads) L.x2[i] = ec[L.agg[i]];
+        __syncthreads();
+        tail_post(L, L.x2, L.x, a.omega);
+        __syncthreads();
+        tail_post(L, L.x, L.x2, a.omega);
+        __syncthreads();
+    }
+}
+
 static int small_grid(int64_t n) { return (int)std::min<int64_t>(1024, std::max<int64_t>(1, (n + kBlock - 1) / kBlock)); }
 
 // Refresh the coarse operators from the Jacobian just assembled (d_vals, d_dinv).
@@ -228,6 +309,11 @@ hipError_t amg_vcycle(Ctx* c, const double* rin, double* zout) {
     auto rhs = [&](size_t l) -> const double* { return l == 0 ? rin : H.lv[l].r; };
     auto bufA = [&](size_t l) { return l == 0 ? zout : H.lv[l].x2; };       // where the level's result lands
     auto bufB = [&](size_t l) { return l == 0 ? H.x0 : H.lv[l].x; };
+    // first level handled by the single-workgroup tail (levels that exchange ghosts never are)
+    size_t lt = nx;
+    while (lt > 1 && H.lv[lt - 1].n <= kTailRows && !(H.distributed && (int)(lt - 1) < H.halo_levels) &&
+           nx - (lt - 1) <= (size_t)kTailMaxLevels)
+        --lt;
     if (c->n_loc > c->n_own && !(H.distributed && H.halo_levels > 0)) {
         // block-local smoothing on the finest level: the output vector's ghost entries (left over from the Krylov
         // loop's own exchange) must read as zero, or the preconditioner would change from call to call
@@ -236,7 +322,7 @@ hipError_t amg_vcycle(Ctx* c, const double* rin, double* zout) {
     }
     {
         PhaseTimer t(c, SHK_PH_AMG_COARSE);
-        for (size_t l = 0; l < nx; ++l) {
+        for (size_t l = 0; l < lt; ++l) {
             const AmgXfer& X = H.xf[l];
             double* rc = X.dense ? H.cr : H.lv[l + 1].r;
             hipLaunchKernelGGL(k_amg_restrict, dim3(small_grid(X.n_coarse)), dim3(kBlock), 0, c->stream, X.n_coarse,
@@ -244,18 +330,31 @@ hipError_t amg_vcycle(Ctx* c, const double* rin, double* zout) {
         }
     }
     const AmgXfer& XL = H.xf[nx - 1];
+    TailArgs ta;
+    ta.nlev = (int)(nx - lt);
+    for (size_t l = lt; l < nx; ++l) {
+        const AmgLevel& L = H.lv[l];
+        const AmgXfer& X = H.xf[l];
+        ta.lv[l - lt] = TailLevel{L.n, L.nslice, X.n_coarse, L.ptr, L.col, X.agg, X.members, L.vals, L.dinv, L.x, L.x2, L.r};
+    }
+    ta.n_c = XL.n_coarse; ta.row0 = H.distributed ? H.offset : 0; ta.ncols = H.distributed ? H.n_glob : XL.n_coarse;
+    ta.inv = H.cinv; ta.cr = H.cr; ta.cx = H.cx; ta.cglob = H.distributed ? H.cglob : H.cr;
+    ta.omega = kAmgOmega; ta.done = done;
     if (H.distributed) {
-        hipLaunchKernelGGL(k_coarse_scatter, dim3(1), dim3(kBlock), 0, c->stream, XL.n_coarse, H.offset, H.n_glob, H.cr,
-                           H.cglob, done);
+        {
+            PhaseTimer t(c, SHK_PH_AMG_COARSE);
+            if (ta.nlev > 0) hipLaunchKernelGGL(k_amg_tail<1>, dim3(1), dim3(kTailThreads), 0, c->stream, ta);
+            hipLaunchKernelGGL(k_coarse_scatter, dim3(1), dim3(kBlock), 0, c->stream, XL.n_coarse, H.offset, H.n_glob,
+                               H.cr, H.cglob, done);
+        }
         if ((e = allreduce_buffer(c, H.cglob, H.cglob, (size_t)H.n_glob)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_dense_apply, dim3(1), dim3(64), 0, c->stream, XL.n_coarse, H.offset, H.n_glob, H.cinv,
-                           H.cglob, H.cx, done);
+        PhaseTimer t(c, SHK_PH_AMG_COARSE);
+        hipLaunchKernelGGL(k_amg_tail<2>, dim3(1), dim3(kTailThreads), 0, c->stream, ta);
     } else {
         PhaseTimer t(c, SHK_PH_AMG_COARSE);
-        hipLaunchKernelGGL(k_dense_apply, dim3(1), dim3(64), 0, c->stream, XL.n_coarse, 0, XL.n_coarse, H.cinv, H.cr,
-                           H.cx, done);
+        hipLaunchKernelGGL(k_amg_tail<0>, dim3(1), dim3(kTailThreads), 0, c->stream, ta);
     }
-    for (size_t l = nx; l-- > 0;) {
+    for (size_t l = lt; l-- > 0;) {
         const AmgXfer& X = H.xf[l];
         const double* ec = X.dense ? H.cx : H.lv[l + 1].x2;
         {
