@@ -156,19 +156,7 @@ __global__ __launch_bounds__(kBlock) void k_amg_post(const AmgSmoothArgs a) {
     for (int g = sw.begin; g < sw.end; g += sw.step) {
         const int s = 4 * g + wave;
         if (s >= a.A.nslice) break;
-        const int base = __builtin_amdgcn_readfirstlane(a.A.ptr[s]);
-        const int width = (__builtin_amdgcn_readfirstlane(a.A.ptr[s + 1]) - base) >> 6;
-        const double* __restrict__ vp = a.vals + base + lane;
-        const int32_t* __restrict__ cp = a.A.col + base + lane;
-        double sum = 0.0;
-        if (a.A.xcd_local) {
-#pragma unroll 4
-            for (int k = 0; k < width; ++k) sum += vp[k * kSlice] * a.x[cp[k * kSlice]];
-        } else {  // matrix larger than the Infinity Cache: stream it non-temporally, keep x cached
-#pragma unroll 4
-            for (int k = 0; k < width; ++k)
-                sum += __builtin_nontemporal_load(vp + k * kSlice) * a.x[__builtin_nontemporal_load(cp + k * kSlice)];
-        }
+        const double sum = sell_row_sum(a.A, a.vals, a.x, s, lane);
         const int row = s * kSlice + lane;
         if (row < a.A.n_rows) a.xo[row] = a.x[row] + a.omega * a.dinv[row] * (a.r[row] - sum);
     }
@@ -295,7 +283,7 @@ hipError_t amg_numeric_setup(Ctx* c) {
 static DevSell level_sell(const Ctx* c, const AmgHierarchy& H, size_t l) {
     if (l == 0) return c->sell();
     const AmgLevel& L = H.lv[l];
-    return DevSell{L.n, L.n_cols, L.nslice, sell_fits_cache(L.slots), L.ptr, L.col, L.rowlen};
+    return DevSell{L.n, L.n_cols, L.nslice, sell_fits_cache(L.slots), L.ptr, L.col, L.rowlen, L.cbase, L.ptr16, L.col16};
 }
 
 // z = M^-1 r : one V(0,2) cycle.  r and z have the fine level's length; r is not modified.

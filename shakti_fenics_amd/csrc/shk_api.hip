@@ -101,6 +101,9 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
             if ((e = upload(c, &L.ptr, LP.Ac.ptr)) != hipSuccess) return e;
             if ((e = upload(c, &L.col, LP.Ac.col)) != hipSuccess) return e;
             if ((e = upload(c, &L.rowlen, LP.Ac.rowlen)) != hipSuccess) return e;
+            if ((e = upload(c, &L.cbase, LP.Ac.cbase)) != hipSuccess) return e;
+            if ((e = upload(c, &L.ptr16, LP.Ac.ptr16)) != hipSuccess) return e;
+            if ((e = upload(c, &L.col16, LP.Ac.col16)) != hipSuccess) return e;
             if ((e = upload(c, &L.diag_slot, LP.diag_slot)) != hipSuccess) return e;
             const size_t nr = std::max<size_t>((size_t)L.nslice * kSlice, (size_t)L.n_cols);
             if ((e = dev_alloc(c, &L.vals, (size_t)L.slots)) != hipSuccess) return e;
@@ -204,6 +207,7 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
         return bail(e, "copy xy");
 #define UP(dst, src) if ((e = upload(c, &c->dst, P.src)) != hipSuccess) return bail(e, "upload " #src)
     UP(d_cells, cells); UP(d_perm, perm); UP(d_sell_ptr, A.ptr); UP(d_sell_col, A.col); UP(d_rowlen, A.rowlen);
+    UP(d_cbase, A.cbase); UP(d_ptr16, A.ptr16); UP(d_col16, A.col16);
     UP(d_lastcell, lastcell); UP(d_blk_slice0, blk_slice0); UP(d_blk_cellptr, blk_cellptr);
     UP(d_blk_cells, blk_cells); UP(d_incptr, incptr); UP(d_inccode, inccode);
 #undef UP

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -61,7 +62,42 @@ struct DevSell {
     const int32_t* ptr;
     const int32_t* col;
     const uint8_t* rowlen;
+    const int32_t* cbase;    // per slice: base column of the 16-bit offsets, or -1
+    const int32_t* ptr16;
+    const uint16_t* col16;
 };
+
+// One SELL-64 slice times x: the lane's row sum.  Four streams: 16- or 32-bit columns, and non-temporal
+// loads when the matrix cannot stay in the Infinity Cache (so that it does not evict x; measured at 10M
+// rows: -10 % time, while a cache-resident matrix is +25 % slower when read non-temporally).
+template <bool NT, class T>
+__device__ __forceinline__ T sell_ld(const T* p) {
+    return NT ? __builtin_nontemporal_load(p) : *p;
+}
+template <bool NT>
+__device__ __forceinline__ double sell_row_sum_t(const DevSell& A, const double* __restrict__ vals,
+                                                 const double* __restrict__ x, int s, int lane) {
+    const int base = __builtin_amdgcn_readfirstlane(A.ptr[s]);
+    const int width = (__builtin_amdgcn_readfirstlane(A.ptr[s + 1]) - base) >> 6;
+    const int cb = __builtin_amdgcn_readfirstlane(A.cbase[s]);
+    const double* __restrict__ vp = vals + base + lane;
+    double sum = 0.0;
+    if (cb >= 0) {
+        const uint16_t* __restrict__ cp = A.col16 + __builtin_amdgcn_readfirstlane(A.ptr16[s]) + lane;
+        const double* __restrict__ xb = x + cb;
+#pragma unroll 4
+        for (int k = 0; k < width; ++k) sum += sell_ld<NT>(vp + k * kSlice) * xb[sell_ld<NT>(cp + k * kSlice)];
+    } else {
+        const int32_t* __restrict__ cp = A.col + base + lane;
+#pragma unroll 4
+        for (int k = 0; k < width; ++k) sum += sell_ld<NT>(vp + k * kSlice) * x[sell_ld<NT>(cp + k * kSlice)];
+    }
+    return sum;
+}
+__device__ __forceinline__ double sell_row_sum(const DevSell& A, const double* __restrict__ vals,
+                                               const double* __restrict__ x, int s, int lane) {
+    return A.xcd_local ? sell_row_sum_t<false>(A, vals, x, s, lane) : sell_row_sum_t<true>(A, vals, x, s, lane);
+}
 
 struct AsmArgs {
     Mesh m;
@@ -82,13 +118,18 @@ struct AsmArgs {
     QuadArg quad;
 };
 
-inline int32_t sell_fits_cache(int64_t slots) { return slots * 12 < (int64_t)192 << 20 ? 1 : 0; }
+inline int32_t sell_fits_cache(int64_t slots) {
+    static const int force = getenv("SHK_XCD") ? atoi(getenv("SHK_XCD")) : -1;  // experiment switch: 0 / 1 / 2
+    if (force >= 0) return force;
+    return slots * 12 < (int64_t)192 << 20 ? 1 : 0;
+}
 
 // Multigrid hierarchy on the device (shk_amg.hip).  Level 0 is the Jacobian itself (Ctx::d_vals, d_dinv).
 struct AmgLevel {
     int32_t n = 0, n_cols = 0, nslice = 0;
     int64_t slots = 0;
-    int32_t *ptr = nullptr, *col = nullptr, *diag_slot = nullptr;
+    int32_t *ptr = nullptr, *col = nullptr, *diag_slot = nullptr, *cbase = nullptr, *ptr16 = nullptr;
+    uint16_t* col16 = nullptr;
     uint8_t* rowlen = nullptr;
     double *vals = nullptr, *dinv = nullptr, *x = nullptr, *x2 = nullptr, *r = nullptr;
 };
@@ -161,6 +202,8 @@ struct Ctx {
     double bc_value = 0.0;
     int32_t *d_sell_ptr = nullptr, *d_sell_col = nullptr, *d_lastcell = nullptr;
     uint8_t* d_rowlen = nullptr;
+    int32_t *d_cbase = nullptr, *d_ptr16 = nullptr;
+    uint16_t* d_col16 = nullptr;
     int32_t *d_blk_slice0 = nullptr, *d_blk_cellptr = nullptr, *d_blk_cells = nullptr, *d_incptr = nullptr;
     uint16_t* d_inccode = nullptr;
     int nblk = 0;
@@ -193,7 +236,7 @@ struct Ctx {
 
     DevSell sell() const {
         return DevSell{(int32_t)n_own, (int32_t)n_loc, plan.A.nslice, sell_fits_cache(slots), d_sell_ptr, d_sell_col,
-                       d_rowlen};
+                       d_rowlen, d_cbase, d_ptr16, d_col16};
     }
 };
 

@@ -320,19 +320,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const SpmvArgs a) {
     for (int g = sw.begin; g < sw.end; g += sw.step) {
         const int s = 4 * g + wave;
         if (s >= a.A.nslice) break;
-        const int base = __builtin_amdgcn_readfirstlane(a.A.ptr[s]);
-        const int width = (__builtin_amdgcn_readfirstlane(a.A.ptr[s + 1]) - base) >> 6;
-        const double* __restrict__ vp = a.vals + base + lane;
-        const int32_t* __restrict__ cp = a.A.col + base + lane;
-        double sum = 0.0;
-        if (a.A.xcd_local) {
-#pragma unroll 4
-            for (int k = 0; k < width; ++k) sum += vp[k * kSlice] * a.x[cp[k * kSlice]];
-        } else {  // matrix larger than the Infinity Cache: stream it non-temporally, keep x cached
-#pragma unroll 4
-            for (int k = 0; k < width; ++k)
-                sum += __builtin_nontemporal_load(vp + k * kSlice) * a.x[__builtin_nontemporal_load(cp + k * kSlice)];
-        }
+        const double sum = sell_row_sum(a.A, a.vals, a.x, s, lane);
         const int row = s * kSlice + lane;
         if (row < a.A.n_rows) {
             a.y[row] = sum;

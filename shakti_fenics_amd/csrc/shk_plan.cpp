@@ -9,6 +9,37 @@
 
 namespace shk {
 
+void SellPattern::build_col16() {
+    cbase.assign(nslice, -1);
+    ptr16.assign(nslice + 1, 0);
+    col16.clear();
+    for (int32_t s = 0; s < nslice; ++s) {
+        const int32_t base = ptr[s], w = (ptr[s + 1] - base) / kSlice;
+        int32_t lo = INT32_MAX, hi = -1;
+        for (int l = 0; l < kSlice; ++l) {
+            const int64_t row = (int64_t)s * kSlice + l;
+            if (row >= n_rows) continue;
+            for (int k = 0; k < rowlen[row]; ++k) {
+                const int32_t c = col[base + k * kSlice + l];
+                lo = std::min(lo, c);
+                hi = std::max(hi, c);
+            }
+        }
+        if (hi >= lo && hi - lo <= 65535) {
+            cbase[s] = lo;
+            for (int k = 0; k < w; ++k)
+                for (int l = 0; l < kSlice; ++l) {
+                    const int64_t row = (int64_t)s * kSlice + l;
+                    const bool real = row < n_rows && k < rowlen[row];
+                    // padding entries carry a zero value: any in-range column will do
+                    const int32_t c = real ? col[base + k * kSlice + l] : (row < n_rows ? (int32_t)row : lo);
+                    col16.push_back((uint16_t)(c - lo));
+                }
+        }
+        ptr16[s + 1] = (int32_t)col16.size();
+    }
+}
+
 // k-d tree order: recursive splits along the longer side of the bounding box.  Split positions are
 // multiples of the largest power of 4 that keeps both parts non-empty, so every aligned run of 4, 16, 64,
 // ... consecutive vertices is a compact k-d cell: those runs are the multigrid aggregates of every level.
@@ -182,6 +213,8 @@ std::string build_plan(int64_t n_own, int64_t n_loc, int64_t ne, const double* x
         }
     }
 
+    A.build_col16();
+
     // ---- assembly blocks: runs of slices whose incident cells fit the LDS budget ----
     P.slices_max = std::max(1, opt.slices_max);
     P.cells_max = std::min(opt.cells_max, 16383);  // inccode keeps the cell slot in 14 bits
@@ -339,6 +372,7 @@ std::string coarsen(const SellPattern& Af, const std::vector<int32_t>& agg, cons
                 C.col[base + k * kSlice + l] = (k < C.rowlen[I]) ? ci[rp[I] + k] : I;
             L.diag_slot[I] = base + l;
         }
+        C.build_col16();
         nslots_c = slots;
         for (int32_t i = 0; i < nf; ++i) {
             const int32_t s = i / kSlice, l = i % kSlice, base = Af.ptr[s], I = agg[i];
