@@ -401,6 +401,43 @@ std::string coarsen(const SellPattern& Af, const std::vector<int32_t>& agg, cons
     return std::string();
 }
 
+// Same, but the coarse rows are first renumbered inside 256-row windows by decreasing length (like the finest
+// level), which removes most of the SELL padding of the coarse operators (47 % -> a few % on level 1).
+// `krank_out[I]` is the k-d position of coarse row I: the next level aggregates runs of 4 of THOSE, which stay
+// inside one window.  Only for hierarchies without ghost columns (neighbours would need the new numbering).
+static std::string coarsen_sorted(const SellPattern& Af, const std::vector<int32_t>& agg,
+                                  const std::vector<int32_t>& colmap, int32_t n_coarse, AmgLevelPlan& L,
+                                  std::vector<int32_t>& krank_out) {
+    const int32_t nf = Af.n_rows;
+    std::vector<std::vector<int32_t>> rows(n_coarse);
+    for (int32_t i = 0; i < nf; ++i) {
+        const int32_t s = i / kSlice, l = i % kSlice, base = Af.ptr[s];
+        auto& r = rows[agg[i]];
+        for (int k = 0; k < Af.rowlen[i]; ++k) {
+            const int32_t J = colmap[Af.col[base + k * kSlice + l]];
+            if (J >= 0) r.push_back(J);
+        }
+    }
+    std::vector<int32_t> len(n_coarse);
+    for (int32_t I = 0; I < n_coarse; ++I) {
+        auto& r = rows[I];
+        std::sort(r.begin(), r.end());
+        len[I] = (int32_t)(std::unique(r.begin(), r.end()) - r.begin());
+        std::vector<int32_t>().swap(r);
+    }
+    krank_out.resize(n_coarse);
+    std::iota(krank_out.begin(), krank_out.end(), 0);
+    for (int32_t w0 = 0; w0 < n_coarse; w0 += 256)
+        std::stable_sort(krank_out.begin() + w0, krank_out.begin() + std::min(n_coarse, w0 + 256),
+                         [&](int32_t a, int32_t b) { return len[a] > len[b]; });
+    std::vector<int32_t> inv(n_coarse);
+    for (int32_t I = 0; I < n_coarse; ++I) inv[krank_out[I]] = I;
+    std::vector<int32_t> agg2(agg.size()), colmap2(colmap.size());
+    for (size_t i = 0; i < agg.size(); ++i) agg2[i] = inv[agg[i]];
+    for (size_t c = 0; c < colmap.size(); ++c) colmap2[c] = colmap[c] >= 0 ? inv[colmap[c]] : -1;
+    return coarsen(Af, agg2, colmap2, n_coarse, n_coarse, false, L);
+}
+
 // Block-local hierarchy of the owned diagonal block (ghost columns dropped): needs no communication.
 std::string build_amg(HostPlan& P, const PlanOptions& opt) {
     P.amg.clear();
@@ -414,12 +451,15 @@ std::string build_amg(HostPlan& P, const PlanOptions& opt) {
         P.amg.emplace_back();
         colmap.assign(Af->n_cols, -1);
         std::copy(agg.begin(), agg.end(), colmap.begin());
-        std::string err = coarsen(*Af, agg, colmap, nc, nc, nc <= coarsest, P.amg.back());
+        const bool dense = nc <= coarsest;
+        std::vector<int32_t> kr;
+        std::string err = dense ? coarsen(*Af, agg, colmap, nc, nc, true, P.amg.back())
+                                : coarsen_sorted(*Af, agg, colmap, nc, P.amg.back(), kr);
         if (!err.empty()) { P.amg.clear(); return "amg: " + err; }
-        if (P.amg.back().dense) break;
+        if (dense) break;
         Af = &P.amg.back().Ac;
         agg.resize(nc);
-        for (int32_t I = 0; I < nc; ++I) agg[I] = I / 4;
+        for (int32_t I = 0; I < nc; ++I) agg[I] = kr[I] / 4;
     }
     return std::string();
 }
