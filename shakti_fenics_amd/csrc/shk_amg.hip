@@ -84,31 +84,39 @@ __global__ __launch_bounds__(kBlock) void k_coarse_scatter(int n, int row0, int 
     for (int j = threadIdx.x; j < ncols; j += kBlock) rglob[j] = (j >= row0 && j < row0 + n) ? rc[j - row0] : 0.0;
 }
 
-// Gauss-Jordan inverse in global memory for the shared coarsest operator (n <= 1024), one workgroup of 1024.
-__global__ __launch_bounds__(1024) void k_dense_invert_big(int n, const double* __restrict__ A, double* __restrict__ M,
-                                                           double* __restrict__ mult) {
+// Gauss-Jordan inverse of a dense coarsest operator with 64 < n <= 1024 rows, in global memory (L2-resident):
+// two launches per pivot -- a single workgroup scales the pivot row and lifts column p out, then the whole
+// chip applies the rank-1 update.  ~6 us per pivot; a one-workgroup version took 140 ms at n = 977.
+__global__ __launch_bounds__(1024) void k_gj_prep(int n, int p, double* __restrict__ M, double* __restrict__ mult,
+                                                  double* __restrict__ prow) {
     const int tid = threadIdx.x;
-    for (int e = tid; e < n * n; e += 1024) M[e] = A[e];
+    const double piv = M[(size_t)p * n + p];
+    const double d = (piv != 0.0) ? 1.0 / piv : 0.0;
+    double m = 0.0;
+    if (tid < n && tid != p) m = M[(size_t)tid * n + p];
     __syncthreads();
+    if (tid < n) {
+        const double v = ((tid == p) ? 1.0 : M[(size_t)p * n + tid]) * d;
+        prow[tid] = v;
+        M[(size_t)p * n + tid] = v;
+        mult[tid] = m;
+        if (tid != p) M[(size_t)tid * n + p] = 0.0;
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_gj_update(int n, int p, double* __restrict__ M,
+                                                      const double* __restrict__ mult, const double* __restrict__ prow) {
+    const int total = n * n;
+    for (int e = blockIdx.x * kBlock + threadIdx.x; e < total; e += gridDim.x * kBlock) {
+        const int i = e / n, j = e - i * n;
+        if (i != p) M[e] -= mult[i] * prow[j];
+    }
+}
+static void dense_invert_big(Ctx* c, int n, const double* A, double* inv, double* scratch /* >= 2n */) {
+    (void)hipMemcpyAsync(inv, A, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
+    const int g = std::min(1024, (n * n + kBlock - 1) / kBlock);
     for (int p = 0; p < n; ++p) {
-        const double piv = M[(size_t)p * n + p];
-        const double d = (piv != 0.0) ? 1.0 / piv : 0.0;
-        __syncthreads();
-        if (tid == 0) M[(size_t)p * n + p] = 1.0;
-        __syncthreads();
-        for (int j = tid; j < n; j += 1024) {
-            M[(size_t)p * n + j] *= d;
-            mult[j] = (j != p) ? M[(size_t)j * n + p] : 0.0;
-        }
-        __syncthreads();
-        for (int j = tid; j < n; j += 1024)
-            if (j != p) M[(size_t)j * n + p] = 0.0;
-        __syncthreads();
-        for (int e = tid; e < n * n; e += 1024) {
-            const int i = e / n, j = e % n;
-            if (i != p) M[e] -= mult[i] * M[(size_t)p * n + j];
-        }
-        __syncthreads();
+        hipLaunchKernelGGL(k_gj_prep, dim3(1), dim3(1024), 0, c->stream, n, p, inv, scratch, scratch + n);
+        hipLaunchKernelGGL(k_gj_update, dim3(g), dim3(kBlock), 0, c->stream, n, p, inv, scratch, scratch + n);
     }
 }
 
@@ -162,6 +170,7 @@ __global__ __launch_bounds__(kBlock) void k_amg_post(const AmgSmoothArgs a) {
     }
 }
 
+
 // ---- tail: every level with <= kTailRows rows runs inside ONE workgroup (restrictions, dense coarsest solve,
 // prolongations and smoothing sweeps separated by workgroup barriers) instead of ~4 tiny launches per level.
 constexpr int kTailRows = 4096;
@@ -183,7 +192,25 @@ struct TailArgs {
     const double* cglob;                 // distributed: gathered coarsest rhs (phase 2), else == cr
     double omega;
     const int* done;
+    int dense_in_tail;                   // 0: the coarsest solve was done by k_dense_gemv before phase 2
 };
+
+// x[i] = sum_j inv[(row0 + i) * ncols + j] * r[j]: one wave per row, over the whole chip (the one-workgroup
+// tail would read a 1024 x 1024 inverse through a single CU: 150 us instead of 5).
+__global__ __launch_bounds__(kBlock) void k_dense_gemv(int n, int row0, int ncols, const double* __restrict__ inv,
+                                                       const double* __restrict__ r, double* __restrict__ x,
+                                                       const int* __restrict__ done) {
+    if (*done) return;
+    const int lane = threadIdx.x & 63;
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += gridDim.x * 4) {
+        const double* row = inv + (size_t)(row0 + i) * ncols;
+        double acc = 0.0;
+        for (int j = lane; j < ncols; j += 64) acc += row[j] * r[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+        if (lane == 0) x[i] = acc;
+    }
+}
 
 __device__ __forceinline__ void tail_post(const TailLevel& L, const double* x, double* xo, double omega) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -219,7 +246,7 @@ __global__ __launch_bounds__(kTailThreads) void k_amg_tail(const TailArgs a) {
         }
     }
     if (PHASE == 1) return;
-    {   // dense coarsest solve: one wave per row, lanes over columns
+    if (a.dense_in_tail) {   // dense coarsest solve: one wave per row, lanes over columns
         const int lane = tid & 63, wave = tid >> 6;
         for (int i = wave; i < a.n_c; i += kTailThreads / 64) {
             const double* row = a.inv + (size_t)(a.row0 + i) * a.ncols;
@@ -246,8 +273,12 @@ __global__ __launch_bounds__(kTailThreads) void k_amg_tail(const TailArgs a) {
 static int small_grid(int64_t n) { return (int)std::min<int64_t>(1024, std::max<int64_t>(1, (n + kBlock - 1) / kBlock)); }
 
 // Refresh the coarse operators from the Jacobian just assembled (d_vals, d_dinv).
-hipError_t amg_numeric_setup(Ctx* c) {
+hipError_t amg_numeric_setup(Ctx* c, bool refresh_dense) {
     AmgHierarchy& H = *c->amg;
+    // a large dense coarsest inverse (2 launches per pivot) is only rebuilt when asked to: between the Newton
+    // iterations of one time step the coarsest operator barely moves, and a slightly stale inverse only makes
+    // the (fixed, linear) preconditioner marginally weaker
+    if (!H.dense_valid) refresh_dense = true;
     PhaseTimer t(c, SHK_PH_OTHER);
     const double* fine = c->d_vals;
     for (size_t l = 0; l < H.xf.size(); ++l) {
@@ -261,12 +292,16 @@ hipError_t amg_numeric_setup(Ctx* c) {
                 hipLaunchKernelGGL(k_galerkin, dim3(small_grid(ns)), dim3(kBlock), 0, c->stream, ns, X.gptr, X.glist,
                                    fine, H.cdense + (size_t)H.offset * H.n_glob);
                 if ((e = allreduce_buffer(c, H.cdense, H.cdense, all)) != hipSuccess) return e;
-                hipLaunchKernelGGL(k_dense_invert_big, dim3(1), dim3(1024), 0, c->stream, H.n_glob, H.cdense, H.cinv,
-                                   H.cglob);
+                if (refresh_dense || H.n_glob <= 64) dense_invert_big(c, H.n_glob, H.cdense, H.cinv, H.gj);
+                H.dense_valid = true;
             } else {
                 hipLaunchKernelGGL(k_galerkin, dim3(small_grid(ns)), dim3(kBlock), 0, c->stream, ns, X.gptr, X.glist,
                                    fine, H.cdense);
-                hipLaunchKernelGGL(k_dense_invert, dim3(1), dim3(kBlock), 0, c->stream, X.n_coarse, H.cdense, H.cinv);
+                if (X.n_coarse <= 64)
+                    hipLaunchKernelGGL(k_dense_invert, dim3(1), dim3(kBlock), 0, c->stream, X.n_coarse, H.cdense, H.cinv);
+                else if (refresh_dense)
+                    dense_invert_big(c, X.n_coarse, H.cdense, H.cinv, H.gj);
+                H.dense_valid = true;
             }
         } else {
             AmgLevel& L = H.lv[l + 1];
@@ -328,6 +363,8 @@ hipError_t amg_vcycle(Ctx* c, const double* rin, double* zout) {
     ta.n_c = XL.n_coarse; ta.row0 = H.distributed ? H.offset : 0; ta.ncols = H.distributed ? H.n_glob : XL.n_coarse;
     ta.inv = H.cinv; ta.cr = H.cr; ta.cx = H.cx; ta.cglob = H.distributed ? H.cglob : H.cr;
     ta.omega = kAmgOmega; ta.done = done;
+    ta.dense_in_tail = ta.ncols <= 128 ? 1 : 0;
+    const int gemv_grid = std::min(256, (ta.n_c + 3) / 4);
     if (H.distributed) {
         {
             PhaseTimer t(c, SHK_PH_AMG_COARSE);
@@ -337,10 +374,19 @@ hipError_t amg_vcycle(Ctx* c, const double* rin, double* zout) {
         }
         if ((e = allreduce_buffer(c, H.cglob, H.cglob, (size_t)H.n_glob)) != hipSuccess) return e;
         PhaseTimer t(c, SHK_PH_AMG_COARSE);
+        if (!ta.dense_in_tail)
+            hipLaunchKernelGGL(k_dense_gemv, dim3(gemv_grid), dim3(kBlock), 0, c->stream, ta.n_c, ta.row0, ta.ncols,
+                               ta.inv, ta.cglob, ta.cx, done);
         hipLaunchKernelGGL(k_amg_tail<2>, dim3(1), dim3(kTailThreads), 0, c->stream, ta);
-    } else {
+    } else if (ta.dense_in_tail) {
         PhaseTimer t(c, SHK_PH_AMG_COARSE);
         hipLaunchKernelGGL(k_amg_tail<0>, dim3(1), dim3(kTailThreads), 0, c->stream, ta);
+    } else {
+        PhaseTimer t(c, SHK_PH_AMG_COARSE);
+        if (ta.nlev > 0) hipLaunchKernelGGL(k_amg_tail<1>, dim3(1), dim3(kTailThreads), 0, c->stream, ta);
+        hipLaunchKernelGGL(k_dense_gemv, dim3(gemv_grid), dim3(kBlock), 0, c->stream, ta.n_c, ta.row0, ta.ncols, ta.inv,
+                           ta.cglob, ta.cx, done);
+        hipLaunchKernelGGL(k_amg_tail<2>, dim3(1), dim3(kTailThreads), 0, c->stream, ta);
     }
     for (size_t l = lt; l-- > 0;) {
         const AmgXfer& X = H.xf[l];
@@ -430,7 +476,7 @@ int amg_setup_distributed(Ctx* c, std::string& err) {
         if ((e = allgather_int(c, (int32_t)n_own, all_n)) != hipSuccess) { err = hipGetErrorString(e); return -1; }
         int32_t maxn = 0;
         for (int32_t v : all_n) maxn = std::max(maxn, v);
-        if (maxn <= 64) { err = "subdomains of <= 64 vertices: nothing to coarsen"; return -1; }
+        if (maxn <= std::max(64, 1024 / R)) { err = "subdomains too small to coarsen"; return -1; }
         std::vector<int32_t> all_nc(R), offs(R + 1, 0);
         int32_t maxnc = 0;
         for (int r = 0; r < R; ++r) {
@@ -438,7 +484,7 @@ int amg_setup_distributed(Ctx* c, std::string& err) {
             maxnc = std::max(maxnc, all_nc[r]);
             offs[r + 1] = offs[r] + all_nc[r];
         }
-        const bool next_dense = maxnc <= 64;
+        const bool next_dense = maxnc <= std::max(64, 1024 / R);  // shared coarsest level of <= 1024 rows
         if (next_dense && offs[R] > 1024) { err = "shared coarsest level larger than 1024 rows (too many subdomains)"; return -1; }
         const int32_t nc_own = all_nc[me];
         const HaloPlan& P = m.plans[cur_plan];

@@ -117,9 +117,10 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
             const size_t cols = (size_t)LP.n_coarse_cols;
             if ((e = dev_alloc(c, &H.cdense, rows * cols)) != hipSuccess) return e;
             if ((e = dev_alloc(c, &H.cinv, rows * cols)) != hipSuccess) return e;
-            if ((e = dev_alloc(c, &H.cr, std::max<size_t>(64, cols))) != hipSuccess) return e;
-            if ((e = dev_alloc(c, &H.cx, 64)) != hipSuccess) return e;
-            if ((e = dev_alloc(c, &H.cglob, std::max<size_t>(64, cols))) != hipSuccess) return e;
+            if ((e = dev_alloc(c, &H.cr, std::max<size_t>(64, std::max(rows, cols)))) != hipSuccess) return e;
+            if ((e = dev_alloc(c, &H.cx, std::max<size_t>(64, rows))) != hipSuccess) return e;
+            if ((e = dev_alloc(c, &H.cglob, std::max<size_t>(64, std::max(rows, cols)))) != hipSuccess) return e;
+            if ((e = dev_alloc(c, &H.gj, 2048)) != hipSuccess) return e;
         }
         LP = AmgLevelPlan();  // host copy no longer needed
     }
@@ -175,6 +176,7 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
     if (const char* s = getenv("SHK_SORT_WINDOW")) opt.sort_window = std::max(64, atoi(s));
     if (const char* s = getenv("SHK_REORDER")) opt.reorder = atoi(s) != 0;
     if (const char* s = getenv("SHK_AMG")) opt.amg = atoi(s) != 0;
+    if (const char* s = getenv("SHK_AMG_COARSEST")) opt.amg_coarsest = atoi(s);
     std::string err = build_plan(c->n_own, c->n_loc, ne, xy, cells, opt, c->plan);
     if (!err.empty()) { delete c; return fail("plan: " + err); }
     const HostPlan& P = c->plan;
@@ -484,9 +486,9 @@ static int read_aux_norm(Ctx* c, double* out) {  // fixed-order host sum of the 
 // Solve A' y = F to  ||F - A' y|| <= max(rtol ||F||, atol)  measured on the TRUE residual: BiCGStab's
 // recursive residual is only trusted to stop an inner run; each run is followed by one explicit
 // residual, and the correction equation is solved again if the target was missed.
-static int krylov_solve(Ctx* c, int* its, int* converged, double* relres) {
+static int krylov_solve(Ctx* c, int* its, int* converged, double* relres, bool first_of_step = true) {
     if (c->use_amg) {
-        HIPCHK(amg_numeric_setup(c));   // Galerkin coarse operators of the Jacobian just assembled
+        HIPCHK(amg_numeric_setup(c, first_of_step));   // Galerkin coarse operators of the Jacobian just assembled
     } else {
         HIPCHK(halo_exchange(c, c->d_dinv));  // ghost columns of A' = A D^-1 need their owners' diagonal
         launch_scale(c);
@@ -575,7 +577,7 @@ int shk_newton_solve(shk_ctx* ctx, double dt, shk_solve_info* info) {
     bool conv = r < c->params.newton_atol;  // relative residual is 1 at iteration 0
     while (!conv && it < c->params.newton_max_it) {
         int k = 0, kc = 0;
-        if (krylov_solve(c, &k, &kc, nullptr)) return -1;
+        if (krylov_solve(c, &k, &kc, nullptr, it == 0)) return -1;
         I.krylov_its += k;
         if (!kc) I.krylov_failed = 1;
         launch_newton_update(c, true);

@@ -146,11 +146,13 @@ struct AmgHierarchy {
     std::vector<AmgXfer> xf;     // [l] : level l -> l+1; the last one lands on the dense coarsest level
     std::vector<int> plan_of;    // distributed: index into Comm::plans of level l's halo plan (size = xf.size())
     bool distributed = false;
+    bool dense_valid = false;    // the dense coarsest inverse has been built at least once
     int halo_levels = 2;         // levels [0, halo_levels) exchange ghosts inside the smoother (SHK_AMG_HALO_LEVELS);
                                  // measured at 1M rows / 4 subdomains: 0 -> 195, 1 -> 144, 2 -> 134, 3 -> 125,
                                  // all -> 110 BiCGStab iterations per Newton step (one subdomain: 138)
     int32_t n_glob = 0, offset = 0;  // dense coarsest operator: n_glob x n_glob, my rows start at `offset`
     double *x0 = nullptr, *cdense = nullptr, *cinv = nullptr, *cr = nullptr, *cx = nullptr, *cglob = nullptr;
+    double* gj = nullptr;        // 2 * 1024 doubles of Gauss-Jordan scratch
     bool ready() const { return !xf.empty(); }
 };
 
@@ -289,7 +291,7 @@ hipError_t halo_exchange(Ctx* c, double* vec);                       // level 0
 hipError_t halo_exchange_plan(Ctx* c, const HaloPlan& P, double* vec);
 hipError_t allreduce_buffer(Ctx* c, const double* src, double* dst, size_t n);  // element-wise sum over subdomains
 int amg_setup_distributed(Ctx* c, std::string& err);  // collective
-hipError_t amg_numeric_setup(Ctx* c);
+hipError_t amg_numeric_setup(Ctx* c, bool refresh_dense);
 hipError_t amg_vcycle(Ctx* c, const double* rin, double* zout);
 // upload one host hierarchy (shk_api.hip: owns the allocation helpers)
 hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H, int64_t n_loc0);

@@ -442,7 +442,8 @@ static std::string coarsen_sorted(const SellPattern& Af, const std::vector<int32
 std::string build_amg(HostPlan& P, const PlanOptions& opt) {
     P.amg.clear();
     P.amg.reserve(40);  // `Af` below points into this vector: no reallocation (4^40 rows is out of reach)
-    const int coarsest = std::min(64, std::max(4, opt.amg_coarsest));
+    // dense coarsest level: up to 1024 rows, but never so large that a small mesh gets no hierarchy at all
+    const int coarsest = std::min(std::min(1024, std::max(4, opt.amg_coarsest)), (int)std::max<int64_t>(64, P.n_own / 16));
     const SellPattern* Af = &P.A;
     std::vector<int32_t> agg(P.n_own), colmap;
     for (int64_t i = 0; i < P.n_own; ++i) agg[i] = P.krank[i] / 4;
