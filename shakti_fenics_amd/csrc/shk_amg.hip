@@ -92,15 +92,13 @@ __global__ __launch_bounds__(1024) void k_gj_prep(int n, int p, double* __restri
     const int tid = threadIdx.x;
     const double piv = M[(size_t)p * n + p];
     const double d = (piv != 0.0) ? 1.0 / piv : 0.0;
-    double m = 0.0;
-    if (tid < n && tid != p) m = M[(size_t)tid * n + p];
+    for (int t = tid; t < n; t += 1024) mult[t] = (t != p) ? M[(size_t)t * n + p] : 0.0;
     __syncthreads();
-    if (tid < n) {
-        const double v = ((tid == p) ? 1.0 : M[(size_t)p * n + tid]) * d;
-        prow[tid] = v;
-        M[(size_t)p * n + tid] = v;
-        mult[tid] = m;
-        if (tid != p) M[(size_t)tid * n + p] = 0.0;
+    for (int t = tid; t < n; t += 1024) {
+        const double v = ((t == p) ? 1.0 : M[(size_t)p * n + t]) * d;
+        prow[t] = v;
+        M[(size_t)p * n + t] = v;
+        if (t != p) M[(size_t)t * n + p] = 0.0;
     }
 }
 __global__ __launch_bounds__(kBlock) void k_gj_update(int n, int p, double* __restrict__ M,
@@ -113,7 +111,7 @@ __global__ __launch_bounds__(kBlock) void k_gj_update(int n, int p, double* __re
 }
 static void dense_invert_big(Ctx* c, int n, const double* A, double* inv, double* scratch /* >= 2n */) {
     (void)hipMemcpyAsync(inv, A, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
-    const int g = std::min(1024, (n * n + kBlock - 1) / kBlock);
+    const int g = std::min(2048, (n * n + kBlock - 1) / kBlock);
     for (int p = 0; p < n; ++p) {
         hipLaunchKernelGGL(k_gj_prep, dim3(1), dim3(1024), 0, c->stream, n, p, inv, scratch, scratch + n);
         hipLaunchKernelGGL(k_gj_update, dim3(g), dim3(kBlock), 0, c->stream, n, p, inv, scratch, scratch + n);
@@ -469,6 +467,10 @@ int amg_setup_distributed(Ctx* c, std::string& err) {
     std::vector<int32_t> agg((size_t)n_own);
     for (int64_t i = 0; i < n_own; ++i) agg[i] = c->plan.krank[i] / 4;
     size_t cur_plan = 0;  // index into m.plans of the current level's halo plan
+    // shared dense coarsest level: same cost rule as the local hierarchy (n^3 <= 250 nnz of the whole matrix,
+    // estimated as R times this subdomain's), split evenly over the subdomains
+    const int glob_dense = std::min(4096, std::max(64, (int)std::cbrt(250.0 * (double)c->nnz * R)));
+    const int per_rank_dense = std::max(16, glob_dense / R);
     H.plan_of.clear();
     hipError_t e;
     for (int level = 0; level < 40; ++level) {
@@ -476,7 +478,7 @@ int amg_setup_distributed(Ctx* c, std::string& err) {
         if ((e = allgather_int(c, (int32_t)n_own, all_n)) != hipSuccess) { err = hipGetErrorString(e); return -1; }
         int32_t maxn = 0;
         for (int32_t v : all_n) maxn = std::max(maxn, v);
-        if (maxn <= std::max(64, 1024 / R)) { err = "subdomains too small to coarsen"; return -1; }
+        if (maxn <= per_rank_dense) { err = "subdomains too small to coarsen"; return -1; }
         std::vector<int32_t> all_nc(R), offs(R + 1, 0);
         int32_t maxnc = 0;
         for (int r = 0; r < R; ++r) {
@@ -484,8 +486,8 @@ int amg_setup_distributed(Ctx* c, std::string& err) {
             maxnc = std::max(maxnc, all_nc[r]);
             offs[r + 1] = offs[r] + all_nc[r];
         }
-        const bool next_dense = maxnc <= std::max(64, 1024 / R);  // shared coarsest level of <= 1024 rows
-        if (next_dense && offs[R] > 1024) { err = "shared coarsest level larger than 1024 rows (too many subdomains)"; return -1; }
+        const bool next_dense = maxnc <= per_rank_dense;
+        if (next_dense && offs[R] > 4608) { err = "shared coarsest level too large (too many subdomains)"; return -1; }
         const int32_t nc_own = all_nc[me];
         const HaloPlan& P = m.plans[cur_plan];
         std::vector<int32_t> gagg;

@@ -120,7 +120,7 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
             if ((e = dev_alloc(c, &H.cr, std::max<size_t>(64, std::max(rows, cols)))) != hipSuccess) return e;
             if ((e = dev_alloc(c, &H.cx, std::max<size_t>(64, rows))) != hipSuccess) return e;
             if ((e = dev_alloc(c, &H.cglob, std::max<size_t>(64, std::max(rows, cols)))) != hipSuccess) return e;
-            if ((e = dev_alloc(c, &H.gj, 2048)) != hipSuccess) return e;
+            if ((e = dev_alloc(c, &H.gj, 2 * std::max<size_t>(1024, std::max(rows, cols)))) != hipSuccess) return e;
         }
         LP = AmgLevelPlan();  // host copy no longer needed
     }

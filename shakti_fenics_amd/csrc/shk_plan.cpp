@@ -442,8 +442,12 @@ static std::string coarsen_sorted(const SellPattern& Af, const std::vector<int32
 std::string build_amg(HostPlan& P, const PlanOptions& opt) {
     P.amg.clear();
     P.amg.reserve(40);  // `Af` below points into this vector: no reallocation (4^40 rows is out of reach)
-    // dense coarsest level: up to 1024 rows, but never so large that a small mesh gets no hierarchy at all
-    const int coarsest = std::min(std::min(1024, std::max(4, opt.amg_coarsest)), (int)std::max<int64_t>(64, P.n_own / 16));
+    // dense coarsest level: as large as its O(n^3) inversion stays small next to the fine-level work
+    // (n^3 <= 250 nnz: 2441 rows at 10M vertices, 977 at 1M), and never so large that a small mesh gets no
+    // hierarchy at all.  Measured at 10M rows: 38 -> 153 -> 610 dense rows = 254 -> 218 -> 165 iterations.
+    const int by_cost = (int)std::cbrt(250.0 * (double)P.A.nnz);
+    const int coarsest = std::min(std::min(std::min(4096, std::max(4, opt.amg_coarsest)), std::max(64, by_cost)),
+                                  (int)std::max<int64_t>(64, P.n_own / 16));
     const SellPattern* Af = &P.A;
     std::vector<int32_t> agg(P.n_own), colmap;
     for (int64_t i = 0; i < P.n_own; ++i) agg[i] = P.krank[i] / 4;

@@ -24,7 +24,7 @@ struct PlanOptions {
     int sort_window = 256; // rows per row-length sorting window (multiple of 64)
     bool reorder = true;   // internal k-d order + window sort (false: keep the caller's numbering)
     bool amg = true;       // also build the aggregation-multigrid hierarchy (of the owned diagonal block)
-    int amg_coarsest = 1024; // largest dense coarsest level of a local hierarchy (inverted by Gauss-Jordan)
+    int amg_coarsest = 4096; // cap of the dense coarsest level of a local hierarchy (inverted by Gauss-Jordan)
 };
 
 // SELL-64 sparsity of the owned rows; columns index owned + ghost vertices.
