@@ -202,8 +202,16 @@ __global__ __launch_bounds__(kBlock) void k_dense_gemv(int n, int row0, int ncol
     const int lane = threadIdx.x & 63;
     for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += gridDim.x * 4) {
         const double* row = inv + (size_t)(row0 + i) * ncols;
-        double acc = 0.0;
-        for (int j = lane; j < ncols; j += 64) acc += row[j] * r[j];
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int j = lane;
+        for (; j + 192 < ncols; j += 256) {  // four independent streams per lane
+            a0 += row[j] * r[j];
+            a1 += row[j + 64] * r[j + 64];
+            a2 += row[j + 128] * r[j + 128];
+            a3 += row[j + 192] * r[j + 192];
+        }
+        for (; j < ncols; j += 64) a0 += row[j] * r[j];
+        double acc = (a0 + a1) + (a2 + a3);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
         if (lane == 0) x[i] = acc;
@@ -362,7 +370,7 @@ hipError_t amg_vcycle(Ctx* c, const double* rin, double* zout) {
     ta.inv = H.cinv; ta.cr = H.cr; ta.cx = H.cx; ta.cglob = H.distributed ? H.cglob : H.cr;
     ta.omega = kAmgOmega; ta.done = done;
     ta.dense_in_tail = ta.ncols <= 128 ? 1 : 0;
-    const int gemv_grid = std::min(256, (ta.n_c + 3) / 4);
+    const int gemv_grid = std::min(2048, (ta.n_c + 3) / 4);
     if (H.distributed) {
         {
             PhaseTimer t(c, SHK_PH_AMG_COARSE);
