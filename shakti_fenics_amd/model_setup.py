@@ -73,7 +73,7 @@ class model_setup:
         self.device = 0
         self.krylov_rtol = 1e-10
         self.krylov_max_it = 20000
-        self.preconditioner = "jacobi"
+        self.preconditioner = "amg"      # "amg" (default) | "amg_local" | "jacobi" (north_star's solver)
 
     def set_lake_bdry(self, outline):
         """1 inside the lake outline, 0 outside (model_setup.py:68-72).  `outline` is an (m,2) polygon,

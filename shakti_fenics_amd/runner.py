@@ -13,7 +13,7 @@ from .synthetic import CONFIGS, N_BDRY, outflow_predicate, synthetic_fields
 
 class SingleRunner:
     def __init__(self, config="c4_10m", order="morton", dt=3600.0, storage=False, moulins=0, device=0,
-                 krylov_rtol=1e-10, shape=None, precond="jacobi"):
+                 krylov_rtol=1e-10, shape=None, precond="amg"):
         nx, ny, Lx, Ly = CONFIGS[config] if shape is None else shape
         self.dom = rectangle_mesh(nx, ny, Lx, Ly, order=order)
         self.dt = dt
@@ -104,7 +104,7 @@ class PartitionedRunner(SingleRunner):
     the global synthetic mesh, keeps its subdomain and joins the communicator."""
 
     def __init__(self, rank, world, device, config="c4_10m", order="morton", dt=3600.0, storage=False,
-                 moulins=0, krylov_rtol=1e-10, shape=None, transport="rccl", group=None, precond="jacobi"):
+                 moulins=0, krylov_rtol=1e-10, shape=None, transport="rccl", group=None, precond="amg"):
         from .distributed import make_context
         from .partition import partition
 
@@ -159,7 +159,7 @@ class PartitionedRunner(SingleRunner):
 def make_runner(args, rank: int, world: int, local_rank: int):
     if world == 1:
         return SingleRunner(args.config, args.order, args.dt, bool(args.storage), args.moulins, local_rank,
-                            args.krylov_rtol, precond=getattr(args, "precond", "jacobi"))
+                            args.krylov_rtol, precond=getattr(args, "precond", "amg"))
     return PartitionedRunner(rank, world, local_rank, args.config, args.order, args.dt, bool(args.storage),
                              args.moulins, args.krylov_rtol, transport=getattr(args, "transport", "rccl"),
-                             precond=getattr(args, "precond", "jacobi"))
+                             precond=getattr(args, "precond", "amg"))

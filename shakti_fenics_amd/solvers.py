@@ -36,7 +36,8 @@ def _upload_inputs(ctx, md, storage, sel=None):
 
 def _configure(ctx, md):
     ctx.set_params(b_min=float(md.b_min), krylov_rtol=float(getattr(md, "krylov_rtol", 1e-10)),
-                   krylov_max_it=int(getattr(md, "krylov_max_it", 20000)))
+                   krylov_max_it=int(getattr(md, "krylov_max_it", 20000)),
+                   precond=_lib.PRECOND[getattr(md, "preconditioner", "amg")])  # collective when md.size > 1
 
 
 class NewtonSolverHIP:
