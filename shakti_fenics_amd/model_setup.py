@@ -22,58 +22,48 @@ def _points_in_polygon(px, py, poly) -> np.ndarray:
     return inside
 
 
-class model_setup:
-    def __init__(self, comm, domain):
-        # communicator (model_setup.py:21-23)
-        self.comm = comm
-        self.rank = comm.Get_rank()
-        self.size = comm.Get_size()
+# (attribute, space, meaning) of the input fields the reference container carries (model_setup.py:44-51)
+_FIELDS = (
+    ("z_b", "V", "bed elevation [m]"),
+    ("z_s", "V", "ice surface elevation [m]"),
+    ("G", "V", "geothermal heat flux [W m^-2]"),
+    ("inputs", "V", "distributed / moulin water input [m s^-1]"),
+    ("b_init", "V", "initial gap height [m]"),
+    ("N_init", "V", "initial effective pressure [Pa]"),
+    ("q_init", "V_flux", "initial water flux [m^2 s^-1]"),
+    ("lake_bdry", "V", "1 inside the lake outline, 0 outside"),
+)
+# scalar / bookkeeping attributes and their defaults (model_setup.py:32,40-41,52-66)
+_DEFAULTS = dict(
+    OutflowBoundary=None, outflow_on=True, storage_on=True, N_bdry=0.0, b_min=1.0e-5, outline=None,
+    lake_name=None, results_name=None, setup_name=None, timesteps=None, nt_save=None, nt_check=None,
+)
+# knobs that exist only in this build (the reference solves with DOLFINx defaults + sparse LU)
+_BUILD_KNOBS = dict(
+    setup_file=None,            # optional path copied next to the results (solvers.py:125)
+    device=0, krylov_rtol=1e-10, krylov_max_it=20000,
+    preconditioner="amg",       # "amg" (default) | "amg_local" | "jacobi" (north_star's solver)
+)
 
-        # domain, mesh, function spaces (model_setup.py:26-32)
+
+class model_setup:
+    """Same attributes, same meaning as the reference's `model_setup(comm, domain)`."""
+
+    def __init__(self, comm, domain):
+        self.comm, self.rank, self.size = comm, comm.Get_rank(), comm.Get_size()
         self.domain = domain
-        self.x = domain.geometry.x[:, 0]
-        self.y = domain.geometry.x[:, 1]
+        coords = domain.geometry.x
+        self.x, self.y = coords[:, 0], coords[:, 1]
         self.V = functionspace(domain, ("CG", 1))
         self.V_flux = functionspace(domain, ("P", 1, (domain.geometry.dim,)))
         self.mask = self.ghost_mask(self.V)
-        self.OutflowBoundary = None
-
-        # bounding box for interpolating gridded data (model_setup.py:35-37)
-        buffer = self.get_buffer()
-        self.bounds = [self.x.min() - buffer, self.x.max() + buffer,
-                       self.y.min() - buffer, self.y.max() + buffer]
-
-        # boundary-condition switches (model_setup.py:40-41)
-        self.outflow_on = True
-        self.storage_on = True
-
-        # physical input functions (model_setup.py:44-53)
-        self.z_b = Function(self.V)
-        self.z_s = Function(self.V)
-        self.G = Function(self.V)
-        self.inputs = Function(self.V)
-        self.b_init = Function(self.V)
-        self.N_init = Function(self.V)
-        self.q_init = Function(self.V_flux)
-        self.lake_bdry = Function(self.V)
-        self.N_bdry = 0.0
-        self.b_min = 1.0e-5
-
-        self.outline = None
-        self.lake_name = None
-        self.results_name = None
-        self.setup_name = None
-        self.setup_file = None     # optional: path copied next to the results (solvers.py:125)
-
-        self.timesteps = None
-        self.nt_save = None
-        self.nt_check = None
-
-        # solver knobs of this build (reference: DOLFINx defaults + exact LU)
-        self.device = 0
-        self.krylov_rtol = 1e-10
-        self.krylov_max_it = 20000
-        self.preconditioner = "amg"      # "amg" (default) | "amg_local" | "jacobi" (north_star's solver)
+        pad = self.get_buffer()   # bounding box for gridded-data interpolation (model_setup.py:35-37)
+        self.bounds = [self.x.min() - pad, self.x.max() + pad, self.y.min() - pad, self.y.max() + pad]
+        for name, space, _ in _FIELDS:
+            setattr(self, name, Function(getattr(self, space), name=name))
+        for table in (_DEFAULTS, _BUILD_KNOBS):
+            for name, value in table.items():
+                setattr(self, name, value)
 
     def set_lake_bdry(self, outline):
         """1 inside the lake outline, 0 outside (model_setup.py:68-72).  `outline` is an (m,2) polygon,

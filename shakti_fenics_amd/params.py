@@ -1,10 +1,22 @@
-"""Physical constants of the SHAKTI model -- same names and values as
-`/root/reference/source/params.py:4-11`, so setup scripts can `from params import rho_i, rho_w, g`."""
-g = 9.81          # gravitational acceleration [m/s^2]
-rho_i = 917       # ice density [kg/m^3]
-rho_w = 1000      # density of water [kg/m^3]
-nu = 1.787e-6     # water viscosity [m^2/s]
-Lh = 3.34e5       # latent heat [J/kg]
-omega = 1e-3      # laminar-turbulent transition parameter of the discharge law
-n = 3             # Glen's flow law exponent
-A = 2.24e-24      # Glen's flow law coefficient [Pa^-n s^-1]
+"""Physical constants of the SHAKTI model, importable by name (`from params import rho_i, rho_w, g`) exactly
+like the reference's module of the same name; values per `/root/reference/source/params.py:4-11`.
+The HIP library receives them through `shk_params` (include/shakti_hip.h)."""
+
+_SI = {
+    # name: (value, unit, meaning)
+    "g": (9.81, "m s^-2", "gravitational acceleration"),
+    "rho_i": (917, "kg m^-3", "density of ice"),
+    "rho_w": (1000, "kg m^-3", "density of water"),
+    "nu": (1.787e-6, "m^2 s^-1", "kinematic viscosity of water"),
+    "Lh": (3.34e5, "J kg^-1", "latent heat of fusion"),
+    "omega": (1e-3, "-", "laminar/turbulent transition parameter of the discharge law"),
+    "n": (3, "-", "Glen flow-law exponent"),
+    "A": (2.24e-24, "Pa^-n s^-1", "Glen flow-law coefficient"),
+}
+
+globals().update({name: entry[0] for name, entry in _SI.items()})
+__all__ = sorted(_SI)
+
+
+def describe() -> str:
+    return "\n".join(f"{k:6s} = {v[0]:<10g} [{v[1]}]  {v[2]}" for k, v in _SI.items())
