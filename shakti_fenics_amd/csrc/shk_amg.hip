@@ -146,11 +146,11 @@ __global__ __launch_bounds__(kBlock) void k_amg_restrict(int32_t n_coarse, const
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_amg_prolong(int32_t n, const int32_t* __restrict__ agg,
+__global__ __launch_bounds__(kBlock) void k_amg_prolong(int32_t n, double alpha, const int32_t* __restrict__ agg,
                                                         const double* __restrict__ ec, double* __restrict__ x,
                                                         const int* __restrict__ done) {
     if (*done) return;
-    for (int32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) x[i] = ec[agg[i]];
+    for (int32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) x[i] = alpha * ec[agg[i]];
 }
 
 // FINE only gives the finest level its own symbol, so that profilers report its launches separately
@@ -188,7 +188,7 @@ struct TailArgs {
     const double* inv;
     double *cr, *cx;
     const double* cglob;                 // distributed: gathered coarsest rhs (phase 2), else == cr
-    double omega;
+    double omega, alpha;
     const int* done;
     int dense_in_tail;                   // 0: the coarsest solve was done by k_dense_gemv before phase 2
 };
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(kTailThreads) void k_amg_tail(const TailArgs a) {
     for (int k = a.nlev - 1; k >= 0; --k) {
         const TailLevel& L = a.lv[k];
         const double* ec = (k + 1 < a.nlev) ? a.lv[k + 1].x2 : a.cx;
-        for (int i = tid; i < L.n; i += kTailThreads) L.x2[i] = ec[L.agg[i]];
+        for (int i = tid; i < L.n; i += kTailThreads) L.x2[i] = a.alpha * ec[L.agg[i]];
         __syncthreads();
         tail_post(L, L.x2, L.x, a.omega);
         __syncthreads();
@@ -368,7 +368,7 @@ hipError_t amg_vcycle(Ctx* c, const double* rin, double* zout) {
     }
     ta.n_c = XL.n_coarse; ta.row0 = H.distributed ? H.offset : 0; ta.ncols = H.distributed ? H.n_glob : XL.n_coarse;
     ta.inv = H.cinv; ta.cr = H.cr; ta.cx = H.cx; ta.cglob = H.distributed ? H.cglob : H.cr;
-    ta.omega = kAmgOmega; ta.done = done;
+    ta.omega = kAmgOmega; ta.alpha = H.alpha; ta.done = done;
     ta.dense_in_tail = ta.ncols <= 128 ? 1 : 0;
     const int gemv_grid = std::min(2048, (ta.n_c + 3) / 4);
     if (H.distributed) {
@@ -399,8 +399,8 @@ hipError_t amg_vcycle(Ctx* c, const double* rin, double* zout) {
         const double* ec = X.dense ? H.cx : H.lv[l + 1].x2;
         {
             PhaseTimer t(c, SHK_PH_AMG_COARSE);
-            hipLaunchKernelGGL(k_amg_prolong, dim3(small_grid(X.n_fine)), dim3(kBlock), 0, c->stream, X.n_fine, X.agg,
-                               ec, bufA(l), done);
+            hipLaunchKernelGGL(k_amg_prolong, dim3(small_grid(X.n_fine)), dim3(kBlock), 0, c->stream, X.n_fine, H.alpha,
+                               X.agg, ec, bufA(l), done);
         }
         AmgSmoothArgs a;
         a.A = level_sell(c, H, l);

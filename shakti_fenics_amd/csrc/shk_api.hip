@@ -124,6 +124,7 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
         }
         LP = AmgLevelPlan();  // host copy no longer needed
     }
+    if (const char* sa = getenv("SHK_AMG_ALPHA")) H.alpha = atof(sa);
     if ((e = dev_alloc(c, &H.x0, (size_t)n_loc0)) != hipSuccess) return e;
     return hipMemset(H.x0, 0, (size_t)n_loc0 * sizeof(double));
 }

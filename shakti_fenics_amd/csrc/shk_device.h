@@ -146,6 +146,9 @@ struct AmgHierarchy {
     std::vector<AmgXfer> xf;     // [l] : level l -> l+1; the last one lands on the dense coarsest level
     std::vector<int> plan_of;    // distributed: index into Comm::plans of level l's halo plan (size = xf.size())
     bool distributed = false;
+    double alpha = 1.4;          // over-correction x = alpha * P e_c: piecewise-constant prolongation under-estimates
+                                 // the coarse correction.  Measured ms/step at 10M | 1M rows: alpha 1.0: 870 | 108,
+                                 // 1.3: 641 | 81, 1.5: 646 | 81, 1.7: 703 | 80, 2.0: 899 | 92   (SHK_AMG_ALPHA)
     bool dense_valid = false;    // the dense coarsest inverse has been built at least once
     int halo_levels = 2;         // levels [0, halo_levels) exchange ghosts inside the smoother (SHK_AMG_HALO_LEVELS);
                                  // measured at 1M rows / 4 subdomains: 0 -> 195, 1 -> 144, 2 -> 134, 3 -> 125,
