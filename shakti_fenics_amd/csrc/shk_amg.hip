@@ -284,7 +284,16 @@ hipError_t amg_numeric_setup(Ctx* c, bool refresh_dense) {
     // a large dense coarsest inverse (2 launches per pivot) is only rebuilt when asked to: between the Newton
     // iterations of one time step the coarsest operator barely moves, and a slightly stale inverse only makes
     // the (fixed, linear) preconditioner marginally weaker
+    // ... and across time steps: a big inverse (> 512 rows) is rebuilt every `dense_period`-th request, or at
+    // once when the last solve needed 25 % more iterations than the first one after the previous rebuild
+    const AmgXfer& XD = H.xf.back();
+    const int nd = H.distributed ? H.n_glob : XD.n_coarse;
+    if (refresh_dense && H.dense_valid && nd > 512) {
+        const bool degraded = H.its_fresh > 0 && H.its_last > 1.25 * H.its_fresh;
+        if (++H.dense_age < H.dense_period && !degraded) refresh_dense = false;
+    }
     if (!H.dense_valid) refresh_dense = true;
+    if (refresh_dense) { H.dense_age = 0; H.its_fresh = 0; }
     PhaseTimer t(c, SHK_PH_OTHER);
     const double* fine = c->d_vals;
     for (size_t l = 0; l < H.xf.size(); ++l) {

@@ -125,6 +125,7 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
         LP = AmgLevelPlan();  // host copy no longer needed
     }
     if (const char* sa = getenv("SHK_AMG_ALPHA")) H.alpha = atof(sa);
+    if (const char* sa = getenv("SHK_AMG_DENSE_PERIOD")) H.dense_period = std::max(1, atoi(sa));
     if ((e = dev_alloc(c, &H.x0, (size_t)n_loc0)) != hipSuccess) return e;
     return hipMemset(H.x0, 0, (size_t)n_loc0 * sizeof(double));
 }
@@ -517,6 +518,10 @@ static int krylov_solve(Ctx* c, int* its, int* converged, double* relres, bool f
         if (st.breakdown && st.its == 0) break;  // no progress possible
     }
     HIPCHK(hipGetLastError());
+    if (c->use_amg && first_of_step) {  // feedback for the coarsest-inverse refresh policy (like with like:
+        c->amg->its_last = total;       // only the first Newton system of each solve is compared)
+        if (c->amg->its_fresh == 0) c->amg->its_fresh = total;
+    }
     if (its) *its = total;
     if (converged) *converged = conv;
     if (relres) *relres = rhs_norm > 0 ? rt / rhs_norm : 0.0;

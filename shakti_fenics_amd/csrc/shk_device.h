@@ -150,6 +150,8 @@ struct AmgHierarchy {
                                  // the coarse correction.  Measured ms/step at 10M | 1M rows: alpha 1.0: 870 | 108,
                                  // 1.3: 641 | 81, 1.5: 646 | 81, 1.7: 703 | 80, 2.0: 899 | 92   (SHK_AMG_ALPHA)
     bool dense_valid = false;    // the dense coarsest inverse has been built at least once
+    int dense_age = 0, dense_period = 8;   // Newton solves since / between rebuilds of a big inverse (SHK_AMG_DENSE_PERIOD)
+    int its_fresh = 0, its_last = 0;       // Krylov iterations of the first solve after a rebuild / of the last solve
     int halo_levels = 2;         // levels [0, halo_levels) exchange ghosts inside the smoother (SHK_AMG_HALO_LEVELS);
                                  // measured at 1M rows / 4 subdomains: 0 -> 195, 1 -> 144, 2 -> 134, 3 -> 125,
                                  // all -> 110 BiCGStab iterations per Newton step (one subdomain: 138)
