@@ -105,6 +105,7 @@ struct AsmArgs {
     const uint8_t* bcflag;   // nullptr if no Dirichlet dofs
     double bc_value;
     double inv_rwg_dt;       // 1 / (rho_w g dt)
+    int debug_skip;          // tuning experiments only (SHK_ASM_SKIP): 1 = no phase 2a, 2 = no quadrature loop
     DevSell A;
     const int32_t *blk_slice0, *blk_cellptr, *blk_cells, *incptr;
     const uint16_t* inccode;

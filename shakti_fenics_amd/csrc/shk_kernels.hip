@@ -112,7 +112,7 @@ __global__ __launch_bounds__(kBlock) void k_assemble(const AsmArgs a) {
 
         double sK = 0.0, F0 = 0.0, F1 = 0.0, F2 = 0.0;
         double T00 = 0.0, T01 = 0.0, T02 = 0.0, T11 = 0.0, T12 = 0.0, T22 = 0.0;
-        for (int k = 0; k < a.quad.nq; ++k) {
+        for (int k = 0; k < ((a.debug_skip & 2) ? 1 : a.quad.nq); ++k) {
             const double f0 = a.quad.phi0[k], f1 = a.quad.phi1[k], f2 = a.quad.phi2[k];
             const double w = a.quad.w2[k] * area;
             const double Nk = N0 * f0 + N1 * f1 + N2 * f2;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void k_assemble(const AsmArgs a) {
     __syncthreads();
 
     // ---- phase 2a: one thread per SELL slot of the owned slices ----
-    if (WITH_J) {
+    if (WITH_J && !(a.debug_skip & 1)) {
         const int n0 = sp[0], n1 = sp[ns];
         for (int s = n0 + tid; s < n1; s += kBlock) {
             int j = 0;
@@ -252,6 +252,7 @@ static void fill_asm_args(Ctx* c, double dt, AsmArgs& a) {
     a.bcflag = c->has_bc ? c->d_bcflag : nullptr;
     a.bc_value = c->bc_value;
     a.inv_rwg_dt = 1.0 / (c->dp.rwg * dt);
+    { static const int dbg = getenv("SHK_ASM_SKIP") ? atoi(getenv("SHK_ASM_SKIP")) : 0; a.debug_skip = dbg; }
     a.A = c->sell();
     a.blk_slice0 = c->d_blk_slice0; a.blk_cellptr = c->d_blk_cellptr; a.blk_cells = c->d_blk_cells;
     a.incptr = c->d_incptr; a.inccode = c->d_inccode;
