@@ -80,6 +80,24 @@ static int set_quadrature(Ctx* c, int nq, const double* xyw) {
     return 0;
 }
 
+// Radon's 7-point degree-5 rule on the reference triangle (centroid + two S21 orbits), weights sum to 1/2.
+static void set_poly_rule(Ctx* c) {
+    const double r15 = std::sqrt(15.0);
+    const double a1 = (6.0 - r15) / 21.0, a2 = (6.0 + r15) / 21.0;
+    const double w0 = 9.0 / 80.0, w1 = (155.0 - r15) / 2400.0, w2 = (155.0 + r15) / 2400.0;
+    const double pts[7][3] = {{1.0 / 3.0, 1.0 / 3.0, w0},
+                              {a1, a1, w1}, {a1, 1.0 - 2.0 * a1, w1}, {1.0 - 2.0 * a1, a1, w1},
+                              {a2, a2, w2}, {a2, 1.0 - 2.0 * a2, w2}, {1.0 - 2.0 * a2, a2, w2}};
+    QuadArg& q = c->qpoly5;
+    q.nq = 7;
+    for (int k = 0; k < 7; ++k) {
+        q.phi0[k] = 1.0 - pts[k][0] - pts[k][1];
+        q.phi1[k] = pts[k][0];
+        q.phi2[k] = pts[k][1];
+        q.w2[k] = 2.0 * pts[k][2];
+    }
+}
+
 namespace shk {
 hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H, int64_t n_loc0) {
     hipError_t e;
@@ -171,6 +189,7 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
     {
         const double* q = &SHK_QUAD_DEFAULT[0][0];
         if (set_quadrature(c, SHK_NQ_DEFAULT, q)) { delete c; return -1; }
+        set_poly_rule(c);
     }
     PlanOptions opt;
     if (const char* s = getenv("SHK_ASM_SLICES")) opt.slices_max = std::max(1, atoi(s));
@@ -190,7 +209,7 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
     c->np = c->grid;
     {
         const size_t E = P.cells_max, S = P.slices_max;
-        size_t lds = 12 * E * sizeof(double) + 3 * E * sizeof(int) + (S + 1) * sizeof(int) +
+        size_t lds = 12 * E * sizeof(double) + (S + 1) * sizeof(int) +
                      (S * kSlice + 1) * sizeof(int) + (size_t)P.max_inc_per_block * sizeof(uint16_t);
         c->asm_lds = (lds + 15) & ~size_t(15);
         if (c->asm_lds > 160 * 1024) { delete c; return fail("assembly LDS budget exceeds 160 KiB"); }
@@ -213,13 +232,14 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
     UP(d_cells, cells); UP(d_perm, perm); UP(d_sell_ptr, A.ptr); UP(d_sell_col, A.col); UP(d_rowlen, A.rowlen);
     UP(d_cbase, A.cbase); UP(d_ptr16, A.ptr16); UP(d_col16, A.col16);
     UP(d_lastcell, lastcell); UP(d_blk_slice0, blk_slice0); UP(d_blk_cellptr, blk_cellptr);
-    UP(d_blk_cells, blk_cells); UP(d_incptr, incptr); UP(d_inccode, inccode);
+    UP(d_blk_cells, blk_cells); UP(d_incptr, incptr); UP(d_inccode, inccode); UP(d_slotsrc, slotsrc);
 #undef UP
     // the host copies of the big plan arrays are no longer needed (the SELL pattern stays for get_csr)
     c->plan.xy = std::vector<double>();
     c->plan.cells = std::vector<int32_t>();
     c->plan.blk_cells = std::vector<int32_t>();
     c->plan.inccode = std::vector<uint16_t>();
+    c->plan.slotsrc = std::vector<uint32_t>();
     c->plan.incptr = std::vector<int32_t>();
     c->plan.lastcell = std::vector<int32_t>();
     if ((e = dev_alloc(c, &c->d_io, 2 * nl)) != hipSuccess) return bail(e, "alloc io");
@@ -238,6 +258,8 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
     if ((e = dev_alloc(c, &c->d_vals_s, (size_t)c->slots)) != hipSuccess) return bail(e, "alloc vals_s");
     if ((e = dev_alloc(c, &c->d_bcflag, nl)) != hipSuccess) return bail(e, "alloc bcflag");
     if ((e = hipMemset(c->d_bcflag, 0, nl)) != hipSuccess) return bail(e, "memset");
+    if ((e = dev_alloc(c, &c->d_slotbc, (size_t)c->slots)) != hipSuccess) return bail(e, "alloc slotbc");
+    if ((e = hipMemset(c->d_slotbc, 0, (size_t)c->slots)) != hipSuccess) return bail(e, "memset");
     if ((e = dev_alloc(c, &c->d_part, (size_t)P_COUNT * kMaxParts)) != hipSuccess) return bail(e, "alloc partials");
     if ((e = hipMemset(c->d_part, 0, P_COUNT * kMaxParts * sizeof(double))) != hipSuccess) return bail(e, "memset");
     c->d_red = c->d_part;
@@ -379,6 +401,9 @@ int shk_set_dirichlet(shk_ctx* ctx, int64_t n, const int32_t* dofs, double value
         flag[c->plan.iperm[dofs[i]]] = 1;
     }
     HIPCHK(hipMemcpy(c->d_bcflag, flag.data(), (size_t)c->n_loc, hipMemcpyHostToDevice));
+    HIPCHK(hipMemsetAsync(c->d_slotbc, 0, (size_t)c->slots, c->stream));
+    if (n > 0) launch_slot_bc(c);
+    HIPCHK(hipStreamSynchronize(c->stream));
     c->has_bc = n > 0;
     c->bc_value = value;
     c->assembled = false;

@@ -103,9 +103,11 @@ struct AsmArgs {
     Mesh m;
     const double *N, *N_n, *b, *qx, *qy, *z_b, *z_s, *G, *melt_n, *storage, *inputs;
     const uint8_t* bcflag;   // nullptr if no Dirichlet dofs
+    const uint8_t* slotbc;   // per SELL slot: 0 keep, 1 zero, 2 one (nullptr if no Dirichlet dofs)
+    const uint32_t* slotsrc; // per off-diagonal SELL slot: its (at most two) staged cells, 16 bits each:
+                             // (block-local cell slot << 4) | (3 li + lj), 0xFFFF = none
     double bc_value;
     double inv_rwg_dt;       // 1 / (rho_w g dt)
-    int debug_skip;          // tuning experiments only (SHK_ASM_SKIP): 1 = no phase 2a, 2 = no quadrature loop
     DevSell A;
     const int32_t *blk_slice0, *blk_cellptr, *blk_cells, *incptr;
     const uint16_t* inccode;
@@ -116,7 +118,8 @@ struct AsmArgs {
     double* vals;
     double* dinv;            // 1 / diag(J)
     DevParams p;
-    QuadArg quad;
+    QuadArg quad;            // degree-7 rule: the transmissivity integral
+    QuadArg qpoly;           // degree-5 rule (7 points): every polynomial term (quad again if n != 3)
 };
 
 inline int32_t sell_fits_cache(int64_t slots) {
@@ -193,7 +196,7 @@ struct Ctx {
     int64_t n_own = 0, n_loc = 0, ne = 0, nnz = 0, slots = 0;
     shk_params params{};
     DevParams dp{};
-    QuadArg quad{};
+    QuadArg quad{}, qpoly5{};
     HostPlan plan;
     int grid = 0;   // blocks used by grid-stride kernels == length of partial arrays
     // device memory
@@ -205,7 +208,8 @@ struct Ctx {
     double* d_io = nullptr;                   // 2*n_loc staging for permuted field I/O
     double* f[SHK_FIELD_COUNT] = {nullptr};   // SHK_Q slot unused (qx/qy are separate)
     double *d_melt_tmp = nullptr, *d_b_tmp = nullptr, *d_m0 = nullptr;
-    uint8_t* d_bcflag = nullptr;
+    uint8_t *d_bcflag = nullptr, *d_slotbc = nullptr;
+    uint32_t* d_slotsrc = nullptr;
     bool has_bc = false;
     double bc_value = 0.0;
     int32_t *d_sell_ptr = nullptr, *d_sell_col = nullptr, *d_lastcell = nullptr;
@@ -273,6 +277,7 @@ enum { P_RR = 0, P_RHV = 1, P_TS = 2, P_TT = 3, P_RHT = 4, P_RHS = 5, P_AUX = 6,
 // launchers (shk_kernels.hip)
 hipError_t prepare_kernels(Ctx* c);
 void launch_assemble(Ctx* c, double dt);
+void launch_slot_bc(Ctx* c);
 void launch_scale(Ctx* c);
 void launch_spmv_plain(Ctx* c, const double* vals, const double* x, double* y);
 void launch_norm2(Ctx* c, const double* x, double* partials);

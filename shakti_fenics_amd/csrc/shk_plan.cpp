@@ -217,7 +217,8 @@ std::string build_plan(int64_t n_own, int64_t n_loc, int64_t ne, const double* x
 
     // ---- assembly blocks: runs of slices whose incident cells fit the LDS budget ----
     P.slices_max = std::max(1, opt.slices_max);
-    P.cells_max = std::min(opt.cells_max, 16383);  // inccode keeps the cell slot in 14 bits
+    P.cells_max = std::min(opt.cells_max, 4095);   // slotsrc keeps the cell slot in 12 bits
+    P.slotsrc.assign((size_t)A.slots, 0xFFFFFFFFu);
     std::vector<int32_t> mark(ne, -1), slot(ne, 0);
     P.blk_slice0.assign(1, 0);
     P.blk_cellptr.assign(1, 0);
@@ -225,6 +226,7 @@ std::string build_plan(int64_t n_own, int64_t n_loc, int64_t ne, const double* x
     P.incptr.assign(v2c_ptr.begin(), v2c_ptr.begin() + n_own + 1);
     P.inccode.assign(v2c_ptr[n_own], 0);
     int32_t blk = 0, slices_in = 0, cells_in = 0, first_slice = 0;
+    std::string plan_error;
     auto close_block = [&](int32_t slice_end) {
         const size_t c0 = P.blk_cells.size();
         const int64_t ra = (int64_t)first_slice * kSlice, rb = std::min<int64_t>(n_own, (int64_t)slice_end * kSlice);
@@ -244,6 +246,26 @@ std::string build_plan(int64_t n_own, int64_t n_loc, int64_t ne, const double* x
                 P.inccode[k] = (uint16_t)((slot[c] << 2) | li);
                 ++inc;
             }
+        // direct sources of the off-diagonal entries of the block's rows (ascending cell id)
+        for (int64_t v = ra; v < rb; ++v) {
+            const int32_t sl = (int32_t)(v / kSlice), ln = (int32_t)(v % kSlice), base = A.ptr[sl];
+            for (int k = 1; k < A.rowlen[v]; ++k) {
+                const int32_t slot_id = base + k * kSlice + ln, u = A.col[slot_id];
+                uint32_t code[2] = {0xFFFFu, 0xFFFFu};
+                int nsrc = 0;
+                for (int32_t q = v2c_ptr[v]; q < v2c_ptr[v + 1]; ++q) {
+                    const int32_t c = v2c[q];
+                    const int32_t* cv = cells + 3 * (int64_t)c;
+                    const int lj = (cv[0] == u) ? 0 : (cv[1] == u) ? 1 : (cv[2] == u) ? 2 : -1;
+                    if (lj < 0) continue;
+                    const int li = (cv[0] == v) ? 0 : (cv[1] == v) ? 1 : 2;
+                    if (nsrc < 2) code[nsrc] = ((uint32_t)slot[c] << 4) | (uint32_t)(3 * li + lj);
+                    ++nsrc;
+                }
+                if (nsrc < 1 || nsrc > 2) { plan_error = "an edge belongs to more than two cells (non-manifold mesh)"; }
+                P.slotsrc[slot_id] = code[0] | (code[1] << 16);
+            }
+        }
         P.max_inc_per_block = std::max(P.max_inc_per_block, inc);
         P.blk_slice0.push_back(slice_end);
         P.blk_cellptr.push_back((int32_t)P.blk_cells.size());
@@ -271,6 +293,7 @@ std::string build_plan(int64_t n_own, int64_t n_loc, int64_t ne, const double* x
         ++slices_in;
     }
     close_block(A.nslice);
+    if (!plan_error.empty()) return plan_error;
     if (opt.amg) {
         std::string err = build_amg(P, opt);
         if (!err.empty()) return err;

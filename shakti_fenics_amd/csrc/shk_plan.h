@@ -75,6 +75,8 @@ struct HostPlan {
     std::vector<int32_t> blk_cells;    // cell ids, ascending inside a block
     std::vector<int32_t> incptr;       // n_own+1 into inccode
     std::vector<uint16_t> inccode;     // (block-local cell slot << 2) | local vertex index
+    std::vector<uint32_t> slotsrc;     // per SELL slot: the <= 2 staged cells of an off-diagonal entry, 16 bits each:
+                                       // (cell slot << 4) | (3 li + lj); 0xFFFF = none (diagonal / padding: unused)
     int max_inc_per_block = 0;
 };
 
