@@ -11,10 +11,32 @@ from .mesh import rectangle_mesh
 from .synthetic import CONFIGS, N_BDRY, outflow_predicate, synthetic_fields
 
 
+def _pmc_traffic(config, nv):
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950
+    calibration + WRITE_SIZE, separate passes; tools/pmc_probe.py, tools/pmc_to_json.py).  Counters cannot be
+    collected from inside bench.py, so the numbers of the matching configuration are read from profiles/."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
+                        f"pmc_traffic_{config}.json")
+    if not config or not os.path.exists(path):
+        return {}
+    k = json.load(open(path))["kernels"]
+    out = {"source": f"profiles/pmc_traffic_{config}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+    if "amg_fine" in k:
+        out["amg_fine"] = k["amg_fine"]["hbm_bytes"]
+    if "spmv1" in k and "spmv2" in k:
+        out["spmv"] = 0.5 * (k["spmv1"]["hbm_bytes"] + k["spmv2"]["hbm_bytes"])
+    if "assemble" in k:
+        out["assemble"] = k["assemble"]["hbm_bytes"]
+    return out
+
+
 class SingleRunner:
     def __init__(self, config="c4_10m", order="morton", dt=3600.0, storage=False, moulins=0, device=0,
                  krylov_rtol=1e-10, shape=None, precond="amg"):
         nx, ny, Lx, Ly = CONFIGS[config] if shape is None else shape
+        self.config_name = config if shape is None else None
         self.dom = rectangle_mesh(nx, ny, Lx, Ly, order=order)
         self.dt = dt
         sf = synthetic_fields(self.dom, storage_on=storage, moulins=moulins)
@@ -73,12 +95,15 @@ class SingleRunner:
         b_post = 12 * nnz + 4 * (slices + 1) + 32 * nv                  # + r, 1/diag: x' = x + w D^-1 (r - A x)
         b_asm = 12 * self.ne_global + 16 * nv + 88 * nv + 8 * nv + 8 * nnz  # 192 nv
 
+        pmc = _pmc_traffic(getattr(self, "config_name", None), nv)
+
         def leg(phase, nbytes, name):
             n = max(prof[phase]["launches"], 1)
             ms = prof[phase]["ms"] / n
             ach = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             return {"kernel": name, "avg_launch_ms": ms, "launches": prof[phase]["launches"],
-                    "bytes_per_launch": nbytes, "achieved": ach, "frac": ach / peak_gbs}
+                    "bytes_per_launch": nbytes, "achieved": ach, "frac": ach / peak_gbs,
+                    "traffic": pmc.get(phase)}
 
         legs = {"spmv": leg("spmv", b_spmv, "k_spmv<1|2> (SELL-64 SpMV + fused BiCGStab dots)"),
                 "assemble": leg("assemble", b_asm, "k_assemble<true> (fused residual + Jacobian)")}
@@ -88,7 +113,8 @@ class SingleRunner:
         d = legs[dom]
         return {
             "bound": "hbm", "kernel": d["kernel"], "achieved": d["achieved"], "peak": peak_gbs, "unit": "GB/s",
-            "frac": d["frac"], "traffic": None, "bytes_per_launch": d["bytes_per_launch"],
+            "frac": d["frac"], "traffic": d["traffic"], "bytes_per_launch": d["bytes_per_launch"],
+            "traffic_source": pmc.get("source"),
             "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"],
             "kernels": legs,
             "phase_ms": {k: v["ms"] for k, v in prof.items()},
