@@ -138,3 +138,61 @@ def test_errors_are_loud(hip):
     with pytest.raises(hip.ShaktiHipError):
         hip.ShaktiHip(dom.xy, bad)
     ctx.close()
+
+
+def test_moulin_inputs_exercise_the_turbulent_branch(hip):
+    """Point sources large enough that omega * Re >> 1 around them (the laminar-turbulent switch of
+    constitutive.py:13-15 is then in its turbulent regime) -- C5 of SURVEY.md 8d in miniature."""
+    dom, f, bc, g = make_case(nx=41, ny=31, moulins=4)
+    ctx = hip.ShaktiHip(dom.xy, dom.cells)
+    ctx.set_params(precond=hip.PRECOND["amg"])
+    upload(ctx, f, bc, g)
+    prm = O.Params()
+    fo = f.copy()
+    fo.N = fo.N_n.copy()
+    its_gpu, its_cpu = [], []
+    for i in range(4):
+        dt = 0.1 * DT if i == 0 else DT
+        info = ctx.step(dt)
+        n_o, conv_o, _ = O.newton_solve(dom.xy, dom.cells, fo, dt, prm, bc, g)
+        O.update_explicit(dom.xy, dom.cells, fo, dt, prm)
+        assert info.converged and conv_o
+        its_gpu.append(info.newton_its)
+        its_cpu.append(n_o)
+    assert its_gpu == its_cpu
+    q = ctx.get_field("q")
+    assert prm.omega * np.hypot(q[:, 0], q[:, 1]).max() / prm.nu > 1.0   # turbulent factor 1 + omega Re > 2 somewhere
+    assert rel_l2(ctx.get_field("N"), fo.N) < 1e-7 and rel_l2(q, fo.q) < 1e-6 and rel_l2(ctx.get_field("b"), fo.b) < 1e-7
+    ctx.close()
+
+
+def test_no_dirichlet_dofs_and_storage_only(hip):
+    """md.outflow_on = False (solvers.py:19-20): pure Neumann problem, regularised by creep closure + storage."""
+    dom, f, bc, g = make_case(nx=25, ny=21, perturb=True)
+    ctx = hip.ShaktiHip(dom.xy, dom.cells)
+    upload(ctx, f, None)
+    ctx.set_dirichlet(np.zeros(0, dtype=np.int32), 0.0)
+    ctx.assemble(DT)
+    Fo, Jo = O.assemble(dom.xy, dom.cells, f, DT, O.Params())
+    rp, ci, va = ctx.csr()
+    J = sp.csr_matrix((va, ci, rp), shape=Jo.shape)
+    assert rel_l2(ctx.residual(), Fo) < 1e-11 and abs(J - Jo).max() / abs(Jo).max() < 1e-12
+    ctx.close()
+
+
+def test_user_quadrature_table_is_honoured(hip):
+    """shk_set_quadrature: a different exact degree-7 rule changes only the transmissivity integral."""
+    dom, f, bc, g = make_case(nx=17, ny=13, perturb=True)
+    q0 = O.load_quadrature()
+    # a permuted copy of the same rule must give the same numbers; a rotated orbit labelling too
+    perm = np.random.default_rng(3).permutation(len(q0))
+    ctx = hip.ShaktiHip(dom.xy, dom.cells)
+    upload(ctx, f, bc, g)
+    ctx.assemble(DT)
+    F0 = ctx.residual()
+    ctx.set_quadrature(q0[perm])
+    ctx.assemble(DT)
+    assert rel_l2(ctx.residual(), F0) < 1e-13
+    with pytest.raises(hip.ShaktiHipError):
+        ctx.set_quadrature(q0 * 2.0)   # weights no longer sum to 1/2
+    ctx.close()
