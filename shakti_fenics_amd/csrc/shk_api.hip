@@ -522,7 +522,7 @@ static int krylov_solve(Ctx* c, int* its, int* converged, double* relres, bool f
     }
     const double rtol = c->params.krylov_rtol, atol = c->params.krylov_atol;
     int total = 0, conv = 0;
-    double target = 0.0, rhs_norm = 0.0, rt = 0.0;
+    double target = 0.0, rhs_norm = 0.0, rt = 0.0, rt_prev = 0.0;
     const int max_outer = 12;
     for (int outer = 0; outer < max_outer; ++outer) {
         if (outer == 0) { c->cur_rtol2 = rtol * rtol; c->cur_atol2 = atol * atol; }
@@ -541,6 +541,10 @@ static int krylov_solve(Ctx* c, int* its, int* converged, double* relres, bool f
         if (read_aux_norm(c, &rt)) return -1;
         if (!(rt > target)) { conv = std::isfinite(rt) ? 1 : 0; break; }
         if (st.breakdown && st.its == 0) break;  // no progress possible
+        // round-off floor of the true residual (eps * cond(J)): another pass that gained less than 2x will not
+        // get there either -- stop instead of burning the iteration budget (reported as not converged)
+        if (outer > 0 && !(rt < 0.5 * rt_prev)) break;
+        rt_prev = rt;
     }
     HIPCHK(hipGetLastError());
     if (c->use_amg && first_of_step) {  // feedback for the coarsest-inverse refresh policy (like with like:
