@@ -81,7 +81,8 @@ typedef struct shk_solve_info {
 enum shk_phase {
     SHK_PH_ASSEMBLE = 0, SHK_PH_SPMV = 1, SHK_PH_VECTOR = 2, SHK_PH_UPDATE = 3, SHK_PH_OTHER = 4,
     SHK_PH_HALO = 5, SHK_PH_AMG_FINE = 6 /* finest-level smoothing SpMV, k_amg_post<true> */,
-    SHK_PH_AMG_COARSE = 7 /* every other multigrid kernel */, SHK_PH_COUNT = 8
+    SHK_PH_AMG_COARSE = 7 /* every other multigrid kernel */,
+    SHK_PH_AMG_FIRST = 8 /* finest-level first sweep on the A*P operator, k_amg_first<true> */, SHK_PH_COUNT = 9
 };
 typedef struct shk_profile {
     double ms[SHK_PH_COUNT];      /* summed launch durations per phase */
@@ -171,8 +172,9 @@ int shk_time_kernel(shk_ctx* ctx, int32_t phase, int32_t reps, double dt, double
 
 /* Plan statistics for DESIGN.md / bench: n[0]=owned rows n[1]=ne n[2]=nnz n[3]=assembly blocks
  * n[4]=cells computed per assembly incl. cells shared between blocks n[5]=SELL slots (padded nnz)
- * n[6]=device bytes n[7]=max row length */
-int shk_plan_stats(shk_ctx* ctx, int64_t n[8]);
+ * n[6]=device bytes n[7]=max row length n[8]=entries of the finest A*P operator (0 if none)
+ * n[9]=multigrid levels (sparse + dense) n[10]=rows of the dense coarsest level n[11]=reserved */
+int shk_plan_stats(shk_ctx* ctx, int64_t n[12]);
 
 #ifdef __cplusplus
 }

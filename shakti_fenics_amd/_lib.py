@@ -31,7 +31,7 @@ class shk_solve_info(C.Structure):
                 ("krylov_failed", C.c_int32), ("residual0", C.c_double), ("residual", C.c_double)]
 
 
-PHASES = ("assemble", "spmv", "vector", "update", "other", "halo", "amg_fine", "amg_coarse")
+PHASES = ("assemble", "spmv", "vector", "update", "other", "halo", "amg_fine", "amg_coarse", "amg_first")
 PRECOND = dict(jacobi=0, amg=1, amg_local=2)
 
 
@@ -308,7 +308,8 @@ class ShaktiHip:
         return ms.value
 
     def plan_stats(self) -> dict:
-        n = (C.c_int64 * 8)()
+        n = (C.c_int64 * 12)()
         self._check(self.lib.shk_plan_stats(self._h, n))
-        keys = ("nv", "ne", "nnz", "asm_blocks", "asm_cells_computed", "sell_slots", "device_bytes", "max_row_len")
+        keys = ("nv", "ne", "nnz", "asm_blocks", "asm_cells_computed", "sell_slots", "device_bytes", "max_row_len",
+                "ap_nnz", "amg_levels", "amg_dense_rows", "reserved")
         return dict(zip(keys, [int(v) for v in n]))

@@ -169,6 +169,34 @@ __global__ __launch_bounds__(kBlock) void k_amg_post(const AmgSmoothArgs a) {
 }
 
 
+// First smoothing sweep after the prolongation, without ever forming x0 = alpha P e:
+//   x1 = alpha e[agg] + w D^-1 (r - alpha (A P) e)       (A P has ~4 entries per row, e is 4x shorter than x)
+struct AmgFirstArgs {
+    DevSell AP;              // fine rows x coarse columns
+    const double* vals;      // A*P values
+    const double* dinv;
+    const double* r;
+    const double* e;         // coarse correction
+    const int32_t* agg;
+    double* xo;
+    double omega, alpha;
+    const int* done;
+};
+template <bool FINE>
+__global__ __launch_bounds__(kBlock) void k_amg_first(const AmgFirstArgs a) {
+    if (*a.done) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const GroupSweep sw = xcd_sweep((a.AP.nslice + 3) >> 2, a.AP.xcd_local);
+    for (int g = sw.begin; g < sw.end; g += sw.step) {
+        const int s = 4 * g + wave;
+        if (s >= a.AP.nslice) break;
+        const double sum = sell_row_sum(a.AP, a.vals, a.e, s, lane);
+        const int row = s * kSlice + lane;
+        if (row < a.AP.n_rows)
+            a.xo[row] = a.alpha * a.e[a.agg[row]] + a.omega * a.dinv[row] * (a.r[row] - a.alpha * sum);
+    }
+}
+
 // ---- tail: every level with <= kTailRows rows runs inside ONE workgroup (restrictions, dense coarsest solve,
 // prolongations and smoothing sweeps separated by workgroup barriers) instead of ~4 tiny launches per level.
 constexpr int kTailRows = 4096;
@@ -298,6 +326,9 @@ hipError_t amg_numeric_setup(Ctx* c, bool refresh_dense) {
     const double* fine = c->d_vals;
     for (size_t l = 0; l < H.xf.size(); ++l) {
         const AmgXfer& X = H.xf[l];
+        if (X.with_ap)
+            hipLaunchKernelGGL(k_galerkin, dim3(small_grid(X.ap_slots)), dim3(kBlock), 0, c->stream, X.ap_slots,
+                               X.ap_gptr, X.ap_glist, fine, X.ap_vals);
         if (X.dense) {
             const int64_t ns = (int64_t)X.n_coarse * X.n_coarse_cols;  // my rows of the coarsest operator
             if (H.distributed) {
@@ -406,7 +437,8 @@ hipError_t amg_vcycle(Ctx* c, const double* rin, double* zout) {
     for (size_t l = lt; l-- > 0;) {
         const AmgXfer& X = H.xf[l];
         const double* ec = X.dense ? H.cx : H.lv[l + 1].x2;
-        {
+        const bool fused = X.with_ap && !H.distributed;
+        if (!fused) {
             PhaseTimer t(c, SHK_PH_AMG_COARSE);
             hipLaunchKernelGGL(k_amg_prolong, dim3(small_grid(X.n_fine)), dim3(kBlock), 0, c->stream, X.n_fine, H.alpha,
                                X.agg, ec, bufA(l), done);
@@ -417,7 +449,17 @@ hipError_t amg_vcycle(Ctx* c, const double* rin, double* zout) {
         a.rc = nullptr; a.members = nullptr; a.n_coarse = 0; a.omega = kAmgOmega; a.done = done;
         const dim3 g(std::min((a.A.nslice + 3) / 4, 2048));
         const bool halo = H.distributed && (int)l < H.halo_levels;
-        for (int sweep = 0; sweep < 2; ++sweep) {
+        if (fused) {
+            AmgFirstArgs f;
+            f.AP = DevSell{X.n_fine, X.n_coarse_cols, X.ap_nslice, sell_fits_cache(X.ap_slots), X.ap_ptr, X.ap_col,
+                           X.ap_rowlen, X.ap_cbase, X.ap_ptr16, X.ap_col16};
+            f.vals = X.ap_vals; f.dinv = dinv(l); f.r = rhs(l); f.e = ec; f.agg = X.agg; f.xo = bufB(l);
+            f.omega = kAmgOmega; f.alpha = H.alpha; f.done = done;
+            PhaseTimer t(c, l == 0 ? SHK_PH_AMG_FIRST : SHK_PH_AMG_COARSE);
+            if (l == 0) hipLaunchKernelGGL(k_amg_first<true>, g, dim3(kBlock), 0, c->stream, f);
+            else hipLaunchKernelGGL(k_amg_first<false>, g, dim3(kBlock), 0, c->stream, f);
+        }
+        for (int sweep = fused ? 1 : 0; sweep < 2; ++sweep) {
             double* xin = sweep == 0 ? bufA(l) : bufB(l);
             a.x = xin;
             a.xo = sweep == 0 ? bufB(l) : bufA(l);

@@ -112,6 +112,19 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
         if ((e = upload(c, &X.members, LP.members)) != hipSuccess) return e;
         if ((e = upload(c, &X.gptr, LP.gptr)) != hipSuccess) return e;
         if ((e = upload(c, &X.glist, LP.glist)) != hipSuccess) return e;
+        if (LP.with_ap) {
+            X.with_ap = true; X.ap_nslice = LP.AP.nslice; X.ap_slots = LP.AP.slots;
+            if (l == 0) H.ap_nnz0 = LP.AP.nnz;
+            if ((e = upload(c, &X.ap_ptr, LP.AP.ptr)) != hipSuccess) return e;
+            if ((e = upload(c, &X.ap_col, LP.AP.col)) != hipSuccess) return e;
+            if ((e = upload(c, &X.ap_rowlen, LP.AP.rowlen)) != hipSuccess) return e;
+            if ((e = upload(c, &X.ap_cbase, LP.AP.cbase)) != hipSuccess) return e;
+            if ((e = upload(c, &X.ap_ptr16, LP.AP.ptr16)) != hipSuccess) return e;
+            if ((e = upload(c, &X.ap_col16, LP.AP.col16)) != hipSuccess) return e;
+            if ((e = upload(c, &X.ap_gptr, LP.ap_gptr)) != hipSuccess) return e;
+            if ((e = upload(c, &X.ap_glist, LP.ap_glist)) != hipSuccess) return e;
+            if ((e = dev_alloc(c, &X.ap_vals, (size_t)X.ap_slots)) != hipSuccess) return e;
+        }
         if (!LP.dense) {
             if (l + 1 >= nx) return hipErrorInvalidValue;  // a hierarchy must end on a dense level
             AmgLevel& L = H.lv[l + 1];
@@ -816,11 +829,16 @@ int shk_time_kernel(shk_ctx* ctx, int32_t phase, int32_t reps, double dt, double
     return 0;
 }
 
-int shk_plan_stats(shk_ctx* ctx, int64_t n[8]) {
+int shk_plan_stats(shk_ctx* ctx, int64_t n[12]) {
     CHECK_CTX(ctx);
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     n[0] = c->n_own; n[1] = c->ne; n[2] = c->nnz; n[3] = c->nblk; n[4] = c->cells_staged;
     n[5] = c->slots; n[6] = c->device_bytes; n[7] = c->plan.A.max_row_len;
+    const AmgHierarchy& H = c->amg ? *c->amg : c->amg_local;
+    n[8] = (H.ready() && H.xf[0].with_ap) ? H.ap_nnz0 : 0;
+    n[9] = H.ready() ? (int64_t)H.xf.size() + 1 : 0;
+    n[10] = H.ready() ? (H.distributed ? H.n_glob : H.xf.back().n_coarse) : 0;
+    n[11] = 0;
     return 0;
 }
 

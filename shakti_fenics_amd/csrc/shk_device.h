@@ -141,6 +141,15 @@ struct AmgXfer {  // level l -> l+1
     int32_t n_fine = 0, n_coarse = 0, n_coarse_cols = 0;
     int32_t *agg = nullptr, *members = nullptr, *gptr = nullptr, *glist = nullptr;
     bool dense = false;
+    // A*P of the fine level (optional): thinner operator for the first smoothing sweep after the prolongation
+    bool with_ap = false;
+    int32_t ap_nslice = 0;
+    int64_t ap_slots = 0;
+    int32_t *ap_ptr = nullptr, *ap_col = nullptr, *ap_cbase = nullptr, *ap_ptr16 = nullptr, *ap_gptr = nullptr,
+            *ap_glist = nullptr;
+    uint16_t* ap_col16 = nullptr;
+    uint8_t* ap_rowlen = nullptr;
+    double* ap_vals = nullptr;
 };
 // A hierarchy is either block-local (the owned diagonal block of a subdomain, or the whole matrix of a single
 // context: no communication) or distributed (ghost columns kept on every level, per-level halo plans, one
@@ -159,6 +168,7 @@ struct AmgHierarchy {
     int halo_levels = 2;         // levels [0, halo_levels) exchange ghosts inside the smoother (SHK_AMG_HALO_LEVELS);
                                  // measured at 1M rows / 4 subdomains: 0 -> 195, 1 -> 144, 2 -> 134, 3 -> 125,
                                  // all -> 110 BiCGStab iterations per Newton step (one subdomain: 138)
+    int64_t ap_nnz0 = 0;             // stored entries of the finest level's A*P operator
     int32_t n_glob = 0, offset = 0;  // dense coarsest operator: n_glob x n_glob, my rows start at `offset`
     double *x0 = nullptr, *cdense = nullptr, *cinv = nullptr, *cr = nullptr, *cx = nullptr, *cglob = nullptr;
     double* gj = nullptr;        // 2 * 1024 doubles of Gauss-Jordan scratch

@@ -56,6 +56,13 @@ struct AmgLevelPlan {
     std::vector<int32_t> glist;     // fine slots summed into each coarse slot, ascending
     std::vector<int32_t> diag_slot; // n_coarse        : slot of the coarse diagonal (sparse levels)
     bool dense = false;
+    // A*P (fine rows x coarse columns, ~4 entries per row instead of ~7): lets the first smoothing sweep after
+    // the prolongation read a thinner operator and skip the prolongated vector altogether:
+    //   x1 = alpha P e + w D^-1 (r - alpha (A P) e)
+    SellPattern AP;                 // same slicing as the fine level; columns = coarse ids
+    std::vector<int32_t> ap_gptr;   // AP slots+1 into ap_glist
+    std::vector<int32_t> ap_glist;  // fine slots summed into each AP slot, ascending
+    bool with_ap = false;
 };
 
 struct HostPlan {

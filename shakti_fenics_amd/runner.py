@@ -109,6 +109,10 @@ class SingleRunner:
                 "assemble": leg("assemble", b_asm, "k_assemble<true> (fused residual + Jacobian)")}
         if prof["amg_fine"]["launches"]:
             legs["amg_fine"] = leg("amg_fine", b_post, "k_amg_post<true> (finest-level multigrid smoother, SELL-64 SpMV)")
+        if prof.get("amg_first", {}).get("launches"):
+            ap = c.plan_stats()["ap_nnz"]
+            b_first = 12 * ap + 4 * (slices + 1) + 4 * nv + 24 * nv + 2 * nv   # A*P, agg, r / 1/diag / x', e
+            legs["amg_first"] = leg("amg_first", b_first, "k_amg_first<true> (first sweep on the A*P operator)")
         dom = max((k for k in legs if k != "assemble"), key=lambda k: prof[k]["ms"])
         d = legs[dom]
         return {
