@@ -122,10 +122,11 @@ def solve(md):
     dt_ = 0.1 * np.abs(md.timesteps[1] - md.timesteps[0])  # first step is 10x smaller (solvers.py:81)
     dt = Constant(md.domain, dt_)
 
+    restart = bool(getattr(md, "restart", False))  # resume from the frames already in md.results_name
     nodes_x = md.comm.gather(md.x[md.mask] if md.rank == 0 else md.x[:0], root=0)
     nodes_y = md.comm.gather(md.y[md.mask] if md.rank == 0 else md.y[:0], root=0)
     md.comm.barrier()
-    if md.rank == 0:
+    if md.rank == 0 and not restart:
         try:
             os.makedirs(md.results_name, exist_ok=False)
         except FileExistsError:
@@ -145,6 +146,7 @@ def solve(md):
         t_i = np.linspace(0, md.timesteps.max(), nti)
         b_arr, N_arr = np.zeros((nti, nd)), np.zeros((nti, nd))
         qx_arr, qy_arr = np.zeros((nti, nd)), np.zeros((nti, nd))
+        melt_arr = np.zeros((nti, nd))   # extension: the lagged melt rate, needed to resume a run exactly
         np.save(md.results_name + "/t.npy", t_i)
         np.save(md.results_name + "/nodes_x.npy", nodes_x)
         np.save(md.results_name + "/nodes_y.npy", nodes_y)
@@ -160,6 +162,29 @@ def solve(md):
 
     ctx, sub = _make_device_state(md, storage)
     newton_log, krylov_log = np.zeros(nt, dtype=np.int64), np.zeros(nt, dtype=np.int64)
+    i_start = 0
+    if restart:
+        # the reference has no resume path; this one continues bit for bit: the state after
+        # the last saved step is (N, b, q, melt_n) of that frame, and N_n = N
+        state = None
+        if md.rank == 0:
+            prog = np.load(md.results_name + "/progress.npy")
+            jlast, ilast = int(prog[0]) - 1, int(prog[1])
+            if jlast < 0:
+                raise RuntimeError("restart requested but no frame has been written yet")
+            old = {k: np.load(md.results_name + f"/{k}.npy") for k in ("b", "N", "qx", "qy", "melt_n")}
+            for arr, k in ((b_arr, "b"), (N_arr, "N"), (qx_arr, "qx"), (qy_arr, "qy"), (melt_arr, "melt_n")):
+                arr[: jlast + 1] = old[k][: jlast + 1]
+            newton_log[: ilast + 1] = np.load(md.results_name + "/newton_its.npy")[: ilast + 1]
+            krylov_log[: ilast + 1] = np.load(md.results_name + "/krylov_its.npy")[: ilast + 1]
+            state = (jlast, ilast, {k: old[k][jlast] for k in old})
+            j = jlast + 1
+        state = md.comm.bcast(state, root=0)
+        jlast, ilast, fr = state
+        pick = (lambda a: a) if sub is None else (lambda a: a[sub.gid])
+        ctx.set_field("N", pick(fr["N"])); ctx.set_field("N_n", pick(fr["N"])); ctx.set_field("b", pick(fr["b"]))
+        ctx.set_field("q", pick(np.column_stack((fr["qx"], fr["qy"])))); ctx.set_field("melt_n", pick(fr["melt_n"]))
+        i_start = ilast + 1
 
     def gather_field(name):
         a = ctx.get_field(name)
@@ -178,27 +203,34 @@ def solve(md):
         np.save(md.results_name + "/N.npy", N_arr)
         np.save(md.results_name + "/qx.npy", qx_arr)
         np.save(md.results_name + "/qy.npy", qy_arr)
+        np.save(md.results_name + "/melt_n.npy", melt_arr)
         np.save(md.results_name + "/newton_its.npy", newton_log)
         np.save(md.results_name + "/krylov_its.npy", krylov_log)
+        np.save(md.results_name + "/progress.npy", np.array([j, last_saved_step]))
 
-    for i in range(nt):
+    last_saved_step = i_start - 1
+    stop_after = getattr(md, "stop_after_step", None)   # optional: end the run early (tests, queue limits)
+    for i in range(i_start, nt):
         if md.rank == 0 and (i + 1) % 10 == 0:
             print(f"Time step {i+1} of {nt} completed ({(i+1)/nt*100:.1f}%)", end="\r")
             sys.stdout.flush()
         if i > 0:
             dt.value = np.abs(md.timesteps[i] - md.timesteps[i - 1])
+        if stop_after is not None and i > stop_after:
+            break
         info = ctx.step(dt.value)          # Newton solve + q, melt_n, b updates + N_n <- N, all on the GPU
         newton_log[i], krylov_log[i] = info.newton_its, info.krylov_its
         if not info.converged:
             ctx.close()
             raise RuntimeError(f"Newton solver did not converge at time step {i}")
         if i % md.nt_save == 0:
-            fields = [gather_field(k) for k in ("b", "N", "qx", "qy")]
+            fields = [gather_field(k) for k in ("b", "N", "qx", "qy", "melt_n")]
             if md.rank == 0 and j < nti:
-                b_arr[j, :], N_arr[j, :], qx_arr[j, :], qy_arr[j, :] = fields
+                b_arr[j, :], N_arr[j, :], qx_arr[j, :], qy_arr[j, :], melt_arr[j, :] = fields
+                j += 1
+                last_saved_step = i
                 if i % md.nt_check == 0:
                     save_all()             # progress dump (solvers.py:217-223)
-                j += 1
     if md.rank == 0:
         save_all()
     ctx.close()

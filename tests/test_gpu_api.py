@@ -66,3 +66,27 @@ def test_pde_solver_object_api(tmp_path):
     assert converged and conv_o and niter == n_o
     assert rel_l2(N.x.array, fo.N) < 1e-8
     solver.ctx.close()
+
+
+def test_restart_continues_bit_for_bit(tmp_path):
+    """resume from the saved frames (the reference has no restart path)."""
+    from shakti_fenics_amd.setups import setup_synthetic_cooke2 as S
+
+    def fresh(root):
+        md = S.initialize(SerialComm(), nx=31, ny=31, days=8.0 / 24.0, results_root=root)
+        md.nt_check = 1
+        return md
+
+    md = fresh(tmp_path / "full")
+    md.solve()
+    full = {k: np.load(f"{md.results_name}/{k}.npy") for k in ("N", "b", "qx", "qy", "melt_n", "newton_its")}
+    md2 = fresh(tmp_path / "split")
+    md2.stop_after_step = 3
+    md2.solve()
+    part = np.load(f"{md2.results_name}/N.npy")
+    assert np.array_equal(part[:4], full["N"][:4]) and not part[4:].any()
+    md3 = fresh(tmp_path / "split")
+    md3.restart = True
+    md3.solve()
+    for k, ref in full.items():
+        assert np.array_equal(np.load(f"{md3.results_name}/{k}.npy"), ref), k
