@@ -10,28 +10,51 @@
 //   up    k_amg_prolong    x = P e_c ;  k_amg_post x' = x + w D^-1 (r - A x), twice
 // All levels use SELL-64; an aligned group of 4 slices = 256 rows contains, by construction, all 4 members
 // of each of its 64 aggregates.
+//
+// Precision: the cycle is a preconditioner, so its operators (a float copy of the Jacobian, the Galerkin
+// products, A*P) and its vectors are stored in float -- the smoothing sweeps are HBM-bound SpMVs and move
+// half the bytes.  BiCGStab's own vectors, its operator, the true-residual refinement and the dense coarsest
+// solve stay in double; the recurrence uses p^ = M^-1 p exactly as computed, so rounding inside M^-1 changes
+// (marginally) the iteration count, never the solution the stopping test certifies.
+#include <cmath>
+#include <cstdio>
+
 #include "shk_device.h"
 
 namespace shk {
 
-constexpr double kAmgOmega = 0.7;
 
+// coarse[s] = sum of the finer values listed for slot s (ascending fine slot: fixed order), accumulated in double
+template <class TC>
 __global__ __launch_bounds__(kBlock) void k_galerkin(int64_t nslots, const int32_t* __restrict__ gptr,
                                                      const int32_t* __restrict__ glist,
-                                                     const double* __restrict__ fine, double* __restrict__ coarse) {
+                                                     const float* __restrict__ fine, TC* __restrict__ coarse) {
     for (int64_t s = blockIdx.x * (int64_t)kBlock + threadIdx.x; s < nslots; s += (int64_t)gridDim.x * kBlock) {
         double a = 0.0;
-        for (int32_t k = gptr[s]; k < gptr[s + 1]; ++k) a += fine[glist[k]];  // ascending fine slot: fixed order
-        coarse[s] = a;
+        for (int32_t k = gptr[s]; k < gptr[s + 1]; ++k) a += (double)fine[glist[k]];
+        coarse[s] = (TC)a;
     }
 }
 
 __global__ __launch_bounds__(kBlock) void k_diag_inv(int32_t n, const int32_t* __restrict__ diag_slot,
-                                                     const double* __restrict__ vals, double* __restrict__ dinv) {
+                                                     const float* __restrict__ vals, float* __restrict__ dinv) {
     for (int32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        const double d = vals[diag_slot[i]];
-        dinv[i] = (d != 0.0) ? 1.0 / d : 1.0;
+        const float d = vals[diag_slot[i]];
+        dinv[i] = (d != 0.0f) ? 1.0f / d : 1.0f;
     }
+}
+
+// float copies of the Jacobian and of its inverse diagonal (level 0 of the preconditioner)
+__global__ __launch_bounds__(kBlock) void k_narrow(int64_t n, const double* __restrict__ a, float* __restrict__ b) {
+    const int64_t n2 = n >> 1;
+    typedef double dvec2 __attribute__((ext_vector_type(2)));
+    const dvec2* __restrict__ a2 = reinterpret_cast<const dvec2*>(a);
+    float2* __restrict__ b2 = reinterpret_cast<float2*>(b);
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
+        const dvec2 v = __builtin_nontemporal_load(a2 + i);
+        b2[i] = make_float2((float)v.x, (float)v.y);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) b[n - 1] = (float)a[n - 1];
 }
 
 // In-place Gauss-Jordan inverse of the dense coarsest operator (n <= 64) in LDS, one workgroup.  No
@@ -62,26 +85,12 @@ __global__ __launch_bounds__(kBlock) void k_dense_invert(int n, const double* __
     for (int e = tid; e < n * n; e += kBlock) inv[e] = M[(e / n) * 64 + (e % n)];
 }
 
-// x[i] = sum_j inv[(row0 + i) * ncols + j] * r[j] for my n rows of the (possibly shared) coarsest operator
-__global__ __launch_bounds__(64) void k_dense_apply(int n, int row0, int ncols, const double* __restrict__ inv,
-                                                    const double* __restrict__ r, double* __restrict__ x,
-                                                    const int* __restrict__ done) {
-    if (*done) return;
-    const int i = threadIdx.x;
-    if (i < n) {
-        double a = 0.0;
-        const double* row = inv + (size_t)(row0 + i) * ncols;
-        for (int j = 0; j < ncols; ++j) a += row[j] * r[j];
-        x[i] = a;
-    }
-}
-
 // Shared coarsest level: every subdomain contributes its slice of the right-hand side (zeros elsewhere); the
 // element-wise sum over subdomains is then the gathered vector.
-__global__ __launch_bounds__(kBlock) void k_coarse_scatter(int n, int row0, int ncols, const double* __restrict__ rc,
+__global__ __launch_bounds__(kBlock) void k_coarse_scatter(int n, int row0, int ncols, const float* __restrict__ rc,
                                                            double* __restrict__ rglob, const int* __restrict__ done) {
     if (*done) return;
-    for (int j = threadIdx.x; j < ncols; j += kBlock) rglob[j] = (j >= row0 && j < row0 + n) ? rc[j - row0] : 0.0;
+    for (int j = threadIdx.x; j < ncols; j += kBlock) rglob[j] = (j >= row0 && j < row0 + n) ? (double)rc[j - row0] : 0.0;
 }
 
 // Gauss-Jordan inverse of a dense coarsest operator with 64 < n <= 1024 rows, in global memory (L2-resident):
@@ -118,82 +127,84 @@ static void dense_invert_big(Ctx* c, int n, const double* A, double* inv, double
     }
 }
 
-struct AmgSmoothArgs {
-    DevSell A;
-    const double* vals;
-    const double* dinv;
-    const double* r;        // right-hand side of this level
-    const double* x;        // k_amg_post: current iterate
-    double* xo;             // down: w D^-1 r ; post: smoothed iterate
-    double* rc;             // down: restricted residual (coarse rhs)
-    const int32_t* members; // down: 4 fine rows per aggregate
-    int32_t n_coarse;
-    double omega;
-    const int* done;        // Krylov stop flag: once set, every later kernel of the queue returns at once
-};
-
+// r_c = P^T r
+template <class TI>
 __global__ __launch_bounds__(kBlock) void k_amg_restrict(int32_t n_coarse, const int32_t* __restrict__ members,
-                                                         const double* __restrict__ r, double* __restrict__ rc,
+                                                         const TI* __restrict__ r, float* __restrict__ rc,
                                                          const int* __restrict__ done) {
     if (*done) return;
     for (int32_t I = blockIdx.x * kBlock + threadIdx.x; I < n_coarse; I += gridDim.x * kBlock) {
         const int4 m = reinterpret_cast<const int4*>(members)[I];
-        double acc = r[m.x];                      // every aggregate has at least one member
+        TI acc = r[m.x];                          // every aggregate has at least one member
         if (m.y >= 0) acc += r[m.y];
         if (m.z >= 0) acc += r[m.z];
         if (m.w >= 0) acc += r[m.w];
-        rc[I] = acc;
+        rc[I] = (float)acc;
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_amg_prolong(int32_t n, double alpha, const int32_t* __restrict__ agg,
-                                                        const double* __restrict__ ec, double* __restrict__ x,
+template <class TO>
+__global__ __launch_bounds__(kBlock) void k_amg_prolong(int32_t n, float alpha, const int32_t* __restrict__ agg,
+                                                        const float* __restrict__ ec, TO* __restrict__ x,
                                                         const int* __restrict__ done) {
     if (*done) return;
-    for (int32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) x[i] = alpha * ec[agg[i]];
+    for (int32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) x[i] = (TO)(alpha * ec[agg[i]]);
 }
 
+// x' = x + w D^-1 (r - A x).  The finest level reads the Krylov vector r (double) and writes either the scratch
+// iterate (float) or the preconditioned Krylov vector (double); coarser levels are float throughout.
+template <class TX, class TR, class TO>
+struct AmgSmoothArgs {
+    DevSell A;
+    const float* vals;
+    const float* dinv;
+    const TR* r;            // right-hand side of this level
+    const TX* x;            // current iterate
+    TO* xo;                 // smoothed iterate
+    float omega;
+    const int* done;        // Krylov stop flag: once set, every later kernel of the queue returns at once
+};
 // FINE only gives the finest level its own symbol, so that profilers report its launches separately
-template <bool FINE>
-__global__ __launch_bounds__(kBlock) void k_amg_post(const AmgSmoothArgs a) {
+template <bool FINE, class TX, class TR, class TO>
+__global__ __launch_bounds__(kBlock) void k_amg_post(const AmgSmoothArgs<TX, TR, TO> a) {
     if (*a.done) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const GroupSweep sw = xcd_sweep((a.A.nslice + 3) >> 2, a.A.xcd_local);
     for (int g = sw.begin; g < sw.end; g += sw.step) {
         const int s = 4 * g + wave;
         if (s >= a.A.nslice) break;
-        const double sum = sell_row_sum(a.A, a.vals, a.x, s, lane);
+        const auto sum = sell_row_sum(a.A, a.vals, a.x, s, lane);
         const int row = s * kSlice + lane;
-        if (row < a.A.n_rows) a.xo[row] = a.x[row] + a.omega * a.dinv[row] * (a.r[row] - sum);
+        if (row < a.A.n_rows) a.xo[row] = (TO)(a.x[row] + a.omega * a.dinv[row] * (a.r[row] - sum));
     }
 }
 
-
 // First smoothing sweep after the prolongation, without ever forming x0 = alpha P e:
 //   x1 = alpha e[agg] + w D^-1 (r - alpha (A P) e)       (A P has ~4 entries per row, e is 4x shorter than x)
+template <class TR>
 struct AmgFirstArgs {
     DevSell AP;              // fine rows x coarse columns
-    const double* vals;      // A*P values
-    const double* dinv;
-    const double* r;
-    const double* e;         // coarse correction
+    const float* vals;       // A*P values
+    const float* dinv;
+    const TR* r;
+    const float* e;          // coarse correction
     const int32_t* agg;
-    double* xo;
-    double omega, alpha;
+    float* xo;
+    float omega, alpha;
     const int* done;
 };
-template <bool FINE>
-__global__ __launch_bounds__(kBlock) void k_amg_first(const AmgFirstArgs a) {
+template <bool FINE, class TR>
+__global__ __launch_bounds__(kBlock) void k_amg_first(const AmgFirstArgs<TR> a) {
     if (*a.done) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const GroupSweep sw = xcd_sweep((a.AP.nslice + 3) >> 2, a.AP.xcd_local);
     for (int g = sw.begin; g < sw.end; g += sw.step) {
         const int s = 4 * g + wave;
         if (s >= a.AP.nslice) break;
-        const double sum = sell_row_sum(a.AP, a.vals, a.e, s, lane);
+        const float sum = sell_row_sum(a.AP, a.vals, a.e, s, lane);
         const int row = s * kSlice + lane;
         if (row < a.AP.n_rows)
-            a.xo[row] = a.alpha * a.e[a.agg[row]] + a.omega * a.dinv[row] * (a.r[row] - a.alpha * sum);
+            a.xo[row] = a.alpha * a.e[a.agg[row]] + a.omega * a.dinv[row] * ((float)a.r[row] - a.alpha * sum);
     }
 }
 
@@ -206,25 +217,26 @@ constexpr int kTailMaxLevels = 8;
 struct TailLevel {
     int32_t n, nslice, n_coarse;         // rows, slices, rows of the next level
     const int32_t *ptr, *col, *agg, *members;
-    const double *vals, *dinv;
-    double *x, *x2, *r;
+    const float *vals, *dinv;
+    float *x, *x2, *r;
 };
 struct TailArgs {
     int nlev;
     TailLevel lv[kTailMaxLevels];
     int n_c, row0, ncols;                // dense coarsest: my rows, first row, columns
     const double* inv;
-    double *cr, *cx;
-    const double* cglob;                 // distributed: gathered coarsest rhs (phase 2), else == cr
-    double omega, alpha;
+    float *cr, *cx;
+    const double* cglob;                 // distributed: gathered coarsest rhs (phase 2); nullptr: use cr
+    float omega, omega2, alpha;
     const int* done;
     int dense_in_tail;                   // 0: the coarsest solve was done by k_dense_gemv before phase 2
 };
 
 // x[i] = sum_j inv[(row0 + i) * ncols + j] * r[j]: one wave per row, over the whole chip (the one-workgroup
 // tail would read a 1024 x 1024 inverse through a single CU: 150 us instead of 5).
+template <class TR>
 __global__ __launch_bounds__(kBlock) void k_dense_gemv(int n, int row0, int ncols, const double* __restrict__ inv,
-                                                       const double* __restrict__ r, double* __restrict__ x,
+                                                       const TR* __restrict__ r, float* __restrict__ x,
                                                        const int* __restrict__ done) {
     if (*done) return;
     const int lane = threadIdx.x & 63;
@@ -233,25 +245,25 @@ __global__ __launch_bounds__(kBlock) void k_dense_gemv(int n, int row0, int ncol
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
         int j = lane;
         for (; j + 192 < ncols; j += 256) {  // four independent streams per lane
-            a0 += row[j] * r[j];
-            a1 += row[j + 64] * r[j + 64];
-            a2 += row[j + 128] * r[j + 128];
-            a3 += row[j + 192] * r[j + 192];
+            a0 += row[j] * (double)r[j];
+            a1 += row[j + 64] * (double)r[j + 64];
+            a2 += row[j + 128] * (double)r[j + 128];
+            a3 += row[j + 192] * (double)r[j + 192];
         }
-        for (; j < ncols; j += 64) a0 += row[j] * r[j];
+        for (; j < ncols; j += 64) a0 += row[j] * (double)r[j];
         double acc = (a0 + a1) + (a2 + a3);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-        if (lane == 0) x[i] = acc;
+        if (lane == 0) x[i] = (float)acc;
     }
 }
 
-__device__ __forceinline__ void tail_post(const TailLevel& L, const double* x, double* xo, double omega) {
+__device__ __forceinline__ void tail_post(const TailLevel& L, const float* x, float* xo, float omega) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int s = wave; s < L.nslice; s += kTailThreads / 64) {
         const int base = L.ptr[s];
         const int width = (L.ptr[s + 1] - base) >> 6;
-        double sum = 0.0;
+        float sum = 0.0f;
         for (int k = 0; k < width; ++k) sum += L.vals[base + k * kSlice + lane] * x[L.col[base + k * kSlice + lane]];
         const int row = s * kSlice + lane;
         if (row < L.n) xo[row] = x[row] + omega * L.dinv[row] * (L.r[row] - sum);
@@ -267,10 +279,10 @@ __global__ __launch_bounds__(kTailThreads) void k_amg_tail(const TailArgs a) {
     if (PHASE != 2) {
         for (int k = 0; k < a.nlev; ++k) {
             const TailLevel& L = a.lv[k];
-            double* rc = (k + 1 < a.nlev) ? a.lv[k + 1].r : a.cr;
+            float* rc = (k + 1 < a.nlev) ? a.lv[k + 1].r : a.cr;
             for (int I = tid; I < L.n_coarse; I += kTailThreads) {
                 const int4 m = reinterpret_cast<const int4*>(L.members)[I];
-                double acc = L.r[m.x];
+                float acc = L.r[m.x];
                 if (m.y >= 0) acc += L.r[m.y];
                 if (m.z >= 0) acc += L.r[m.z];
                 if (m.w >= 0) acc += L.r[m.w];
@@ -285,26 +297,125 @@ __global__ __launch_bounds__(kTailThreads) void k_amg_tail(const TailArgs a) {
         for (int i = wave; i < a.n_c; i += kTailThreads / 64) {
             const double* row = a.inv + (size_t)(a.row0 + i) * a.ncols;
             double acc = 0.0;
-            for (int j = lane; j < a.ncols; j += 64) acc += row[j] * a.cglob[j];
+            if (a.cglob) for (int j = lane; j < a.ncols; j += 64) acc += row[j] * a.cglob[j];
+            else for (int j = lane; j < a.ncols; j += 64) acc += row[j] * (double)a.cr[j];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-            if (lane == 0) a.cx[i] = acc;
+            if (lane == 0) a.cx[i] = (float)acc;
         }
         __syncthreads();
     }
     for (int k = a.nlev - 1; k >= 0; --k) {
         const TailLevel& L = a.lv[k];
-        const double* ec = (k + 1 < a.nlev) ? a.lv[k + 1].x2 : a.cx;
+        const float* ec = (k + 1 < a.nlev) ? a.lv[k + 1].x2 : a.cx;
         for (int i = tid; i < L.n; i += kTailThreads) L.x2[i] = a.alpha * ec[L.agg[i]];
         __syncthreads();
         tail_post(L, L.x2, L.x, a.omega);
         __syncthreads();
-        tail_post(L, L.x, L.x2, a.omega);
+        tail_post(L, L.x, L.x2, a.omega2);
         __syncthreads();
     }
 }
 
+// One power-iteration step xo = D^-1 A x; with NORMS the workgroups also leave their shares of |xo|^2 and |x|^2
+// in part[0 .. grid) and part[kMaxParts .. kMaxParts + grid) (summed on the host in a fixed order).
+template <bool NORMS>
+__global__ __launch_bounds__(kBlock) void k_power_step(const DevSell A, const float* __restrict__ vals,
+                                                       const float* __restrict__ dinv, const float* __restrict__ x,
+                                                       float* __restrict__ xo, double* __restrict__ part) {
+    __shared__ double sh[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double so = 0.0, sx = 0.0;
+    const GroupSweep sw = xcd_sweep((A.nslice + 3) >> 2, A.xcd_local);
+    for (int g = sw.begin; g < sw.end; g += sw.step) {
+        const int s = 4 * g + wave;
+        if (s >= A.nslice) break;
+        const float sum = sell_row_sum(A, vals, x, s, lane);
+        const int row = s * kSlice + lane;
+        if (row < A.n_rows) {
+            const float y = dinv[row] * sum;
+            xo[row] = y;
+            if (NORMS) { so += (double)y * y; sx += (double)x[row] * x[row]; }
+        }
+    }
+    if (NORMS) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { so += __shfl_down(so, o, 64); sx += __shfl_down(sx, o, 64); }
+        if (lane == 0) { sh[wave] = so; sh[4 + wave] = sx; }
+        __syncthreads();
+        if (tid == 0) {
+            part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+            part[kMaxParts + blockIdx.x] = (sh[4] + sh[5]) + (sh[6] + sh[7]);
+        }
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_power_init(int32_t n, int32_t n_cols, float* __restrict__ x) {
+    for (int32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_cols; i += gridDim.x * kBlock) {
+        uint32_t h = (uint32_t)i * 2654435761u;   // fixed pseudo-random start, ghosts columns stay zero
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        x[i] = i < n ? 0.5f + (float)(h & 0xFFFF) * (1.0f / 65536.0f) * ((h & 0x10000) ? 1.0f : -1.0f) : 0.0f;
+    }
+}
+
 static int small_grid(int64_t n) { return (int)std::min<int64_t>(1024, std::max<int64_t>(1, (n + kBlock - 1) / kBlock)); }
+
+static DevSell level_sell(const Ctx* c, const AmgHierarchy& H, size_t l);
+
+// Largest eigenvalue of D^-1 A over the levels that run as separate launches (the one-workgroup tail levels
+// are coarser Galerkin products of the same operator), by `steps` power iterations each; one host sync.
+static hipError_t estimate_lambda(Ctx* c, AmgHierarchy& H) {
+    constexpr int steps = 16;
+    double lam = 0.0;
+    std::vector<double> h(2 * (size_t)kMaxParts);
+    for (size_t l = 0; l < H.xf.size(); ++l) {
+        if (l > 0 && H.lv[l].n <= 4096) break;
+        const DevSell A = level_sell(c, H, l);
+        const float* vals = l == 0 ? c->d_vals32 : H.lv[l].vals;
+        const float* dinv = l == 0 ? c->d_dinv32 : H.lv[l].dinv;
+        float* xa = l == 0 ? H.x0 : H.lv[l].x;
+        float* xb = l == 0 ? H.x1 : H.lv[l].x2;
+        const int grid = std::min((A.nslice + 3) / 4, 2048);
+        hipLaunchKernelGGL(k_power_init, dim3(std::min(1024, (A.n_cols + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
+                           A.n_rows, A.n_cols, xa);
+        hipError_t e = hipMemsetAsync(xb, 0, (size_t)A.n_cols * sizeof(float), c->stream);
+        if (e != hipSuccess) return e;
+        for (int k = 0; k < steps; ++k) {
+            if (k + 1 < steps)
+                hipLaunchKernelGGL(k_power_step<false>, dim3(grid), dim3(kBlock), 0, c->stream, A, vals, dinv,
+                                   (const float*)xa, xb, c->d_part + (size_t)P_AUX * kMaxParts);
+            else
+                hipLaunchKernelGGL(k_power_step<true>, dim3(grid), dim3(kBlock), 0, c->stream, A, vals, dinv,
+                                   (const float*)xa, xb, c->d_part + (size_t)P_AUX * kMaxParts);
+            std::swap(xa, xb);
+        }
+        if ((e = hipMemcpyAsync(h.data(), c->d_part + (size_t)P_AUX * kMaxParts, 2 * (size_t)kMaxParts * sizeof(double),
+                                hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return e;
+        double so = 0.0, sx = 0.0;
+        for (int b = 0; b < grid; ++b) { so += h[b]; sx += h[kMaxParts + b]; }
+        if (sx > 0.0 && std::isfinite(so)) lam = std::max(lam, std::sqrt(so / sx));
+        // the scratch vectors go back to zero: their ghost columns must read as zero in block-local sweeps
+        if ((e = hipMemsetAsync(xa, 0, (size_t)A.n_cols * sizeof(float), c->stream)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(xb, 0, (size_t)A.n_cols * sizeof(float), c->stream)) != hipSuccess) return e;
+    }
+    // subdomains must agree on the damping: take the largest estimate
+    if (c->comm.kind != Comm::NONE && c->comm.nranks > 1) {
+        const int R = c->comm.nranks;
+        std::vector<double> buf((size_t)R, 0.0);
+        buf[c->comm.rank] = lam;
+        double* d = c->d_part + (size_t)P_AUX * kMaxParts;
+        hipError_t e = hipMemcpyAsync(d, buf.data(), R * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) return e;
+        if ((e = allreduce_buffer(c, d, d, (size_t)R)) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(buf.data(), d, R * sizeof(double), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return e;
+        for (double v : buf) lam = std::max(lam, v);
+        if ((e = hipMemsetAsync(d, 0, R * sizeof(double), c->stream)) != hipSuccess) return e;
+    }
+    H.lambda = lam > 0.0 ? 1.1 * lam : 2.0 / 0.7;   // no estimate: fall back to w = 0.7 ... 
+    if (getenv("SHK_DEBUG")) fprintf(stderr, "[shk] multigrid smoother: lambda_max(D^-1 A) ~ %.4f\n", lam);
+    return hipSuccess;
+}
 
 // Refresh the coarse operators from the Jacobian just assembled (d_vals, d_dinv).
 hipError_t amg_numeric_setup(Ctx* c, bool refresh_dense) {
@@ -323,11 +434,13 @@ hipError_t amg_numeric_setup(Ctx* c, bool refresh_dense) {
     if (!H.dense_valid) refresh_dense = true;
     if (refresh_dense) { H.dense_age = 0; H.its_fresh = 0; }
     PhaseTimer t(c, SHK_PH_OTHER);
-    const double* fine = c->d_vals;
+    hipLaunchKernelGGL(k_narrow, dim3(c->grid), dim3(kBlock), 0, c->stream, c->slots, c->d_vals, c->d_vals32);
+    hipLaunchKernelGGL(k_narrow, dim3(small_grid(c->n_own)), dim3(kBlock), 0, c->stream, c->n_own, c->d_dinv, c->d_dinv32);
+    const float* fine = c->d_vals32;
     for (size_t l = 0; l < H.xf.size(); ++l) {
         const AmgXfer& X = H.xf[l];
         if (X.with_ap)
-            hipLaunchKernelGGL(k_galerkin, dim3(small_grid(X.ap_slots)), dim3(kBlock), 0, c->stream, X.ap_slots,
+            hipLaunchKernelGGL(k_galerkin<float>, dim3(small_grid(X.ap_slots)), dim3(kBlock), 0, c->stream, X.ap_slots,
                                X.ap_gptr, X.ap_glist, fine, X.ap_vals);
         if (X.dense) {
             const int64_t ns = (int64_t)X.n_coarse * X.n_coarse_cols;  // my rows of the coarsest operator
@@ -335,14 +448,14 @@ hipError_t amg_numeric_setup(Ctx* c, bool refresh_dense) {
                 const size_t all = (size_t)H.n_glob * H.n_glob;
                 hipError_t e = hipMemsetAsync(H.cdense, 0, all * sizeof(double), c->stream);
                 if (e != hipSuccess) return e;
-                hipLaunchKernelGGL(k_galerkin, dim3(small_grid(ns)), dim3(kBlock), 0, c->stream, ns, X.gptr, X.glist,
-                                   fine, H.cdense + (size_t)H.offset * H.n_glob);
+                hipLaunchKernelGGL(k_galerkin<double>, dim3(small_grid(ns)), dim3(kBlock), 0, c->stream, ns, X.gptr,
+                                   X.glist, fine, H.cdense + (size_t)H.offset * H.n_glob);
                 if ((e = allreduce_buffer(c, H.cdense, H.cdense, all)) != hipSuccess) return e;
                 if (refresh_dense || H.n_glob <= 64) dense_invert_big(c, H.n_glob, H.cdense, H.cinv, H.gj);
                 H.dense_valid = true;
             } else {
-                hipLaunchKernelGGL(k_galerkin, dim3(small_grid(ns)), dim3(kBlock), 0, c->stream, ns, X.gptr, X.glist,
-                                   fine, H.cdense);
+                hipLaunchKernelGGL(k_galerkin<double>, dim3(small_grid(ns)), dim3(kBlock), 0, c->stream, ns, X.gptr,
+                                   X.glist, fine, H.cdense);
                 if (X.n_coarse <= 64)
                     hipLaunchKernelGGL(k_dense_invert, dim3(1), dim3(kBlock), 0, c->stream, X.n_coarse, H.cdense, H.cinv);
                 else if (refresh_dense)
@@ -351,20 +464,30 @@ hipError_t amg_numeric_setup(Ctx* c, bool refresh_dense) {
             }
         } else {
             AmgLevel& L = H.lv[l + 1];
-            hipLaunchKernelGGL(k_galerkin, dim3(small_grid(L.slots)), dim3(kBlock), 0, c->stream, L.slots, X.gptr,
-                               X.glist, fine, L.vals);
+            hipLaunchKernelGGL(k_galerkin<float>, dim3(small_grid(L.slots)), dim3(kBlock), 0, c->stream, L.slots,
+                               X.gptr, X.glist, fine, L.vals);
             hipLaunchKernelGGL(k_diag_inv, dim3(small_grid(L.n)), dim3(kBlock), 0, c->stream, L.n, L.diag_slot, L.vals,
                                L.dinv);
             fine = L.vals;
         }
     }
+    if (refresh_dense || H.lambda == 0.0) return estimate_lambda(c, H);
     return hipSuccess;
 }
 
 static DevSell level_sell(const Ctx* c, const AmgHierarchy& H, size_t l) {
-    if (l == 0) return c->sell();
+    if (l == 0) return c->sell32();
     const AmgLevel& L = H.lv[l];
-    return DevSell{L.n, L.n_cols, L.nslice, sell_fits_cache(L.slots), L.ptr, L.col, L.rowlen, L.cbase, L.ptr16, L.col16};
+    return DevSell{L.n, L.n_cols, L.nslice, sell_fits_cache(L.slots, kAmgSlotBytes), L.ptr, L.col, L.rowlen, L.cbase,
+                   L.ptr16, L.col16};
+}
+
+template <bool FINE, class TX, class TR, class TO>
+static void launch_post(Ctx* c, const DevSell& A, const float* vals, const float* dinv, const TR* r, const TX* x, TO* xo,
+                        float w, const int* done) {
+    AmgSmoothArgs<TX, TR, TO> a{A, vals, dinv, r, x, xo, w, done};
+    const dim3 g(std::min((A.nslice + 3) / 4, 2048));
+    hipLaunchKernelGGL((k_amg_post<FINE, TX, TR, TO>), g, dim3(kBlock), 0, c->stream, a);
 }
 
 // z = M^-1 r : one V(0,2) cycle.  r and z have the fine level's length; r is not modified.
@@ -372,12 +495,11 @@ hipError_t amg_vcycle(Ctx* c, const double* rin, double* zout) {
     AmgHierarchy& H = *c->amg;
     const size_t nx = H.xf.size();  // levels 0..nx-1 are sparse, level nx is the dense coarsest
     const int* done = &c->d_state->done;
+    static const double fw1 = getenv("SHK_AMG_W1") ? atof(getenv("SHK_AMG_W1")) : 0.0;   // experiment overrides
+    static const double fw2 = getenv("SHK_AMG_W2") ? atof(getenv("SHK_AMG_W2")) : 0.0;
+    const float w1 = (float)(fw1 > 0.0 ? fw1 : H.c1 / H.lambda), w2 = (float)(fw2 > 0.0 ? fw2 : H.c2 / H.lambda);
+    const float alpha = (float)H.alpha, omega = w1;
     hipError_t e;
-    auto vals = [&](size_t l) { return l == 0 ? c->d_vals : H.lv[l].vals; };
-    auto dinv = [&](size_t l) { return l == 0 ? c->d_dinv : H.lv[l].dinv; };
-    auto rhs = [&](size_t l) -> const double* { return l == 0 ? rin : H.lv[l].r; };
-    auto bufA = [&](size_t l) { return l == 0 ? zout : H.lv[l].x2; };       // where the level's result lands
-    auto bufB = [&](size_t l) { return l == 0 ? H.x0 : H.lv[l].x; };
     // first level handled by the single-workgroup tail (levels that exchange ghosts never are)
     size_t lt = nx;
     while (lt > 1 && H.lv[lt - 1].n <= kTailRows && !(H.distributed && (int)(lt - 1) < H.halo_levels) &&
@@ -393,9 +515,13 @@ hipError_t amg_vcycle(Ctx* c, const double* rin, double* zout) {
         PhaseTimer t(c, SHK_PH_AMG_COARSE);
         for (size_t l = 0; l < lt; ++l) {
             const AmgXfer& X = H.xf[l];
-            double* rc = X.dense ? H.cr : H.lv[l + 1].r;
-            hipLaunchKernelGGL(k_amg_restrict, dim3(small_grid(X.n_coarse)), dim3(kBlock), 0, c->stream, X.n_coarse,
-                               X.members, rhs(l), rc, done);
+            float* rc = X.dense ? H.cr : H.lv[l + 1].r;
+            const dim3 g(small_grid(X.n_coarse));
+            if (l == 0)
+                hipLaunchKernelGGL(k_amg_restrict<double>, g, dim3(kBlock), 0, c->stream, X.n_coarse, X.members, rin, rc, done);
+            else
+                hipLaunchKernelGGL(k_amg_restrict<float>, g, dim3(kBlock), 0, c->stream, X.n_coarse, X.members,
+                                   (const float*)H.lv[l].r, rc, done);
         }
     }
     const AmgXfer& XL = H.xf[nx - 1];
@@ -407,8 +533,8 @@ hipError_t amg_vcycle(Ctx* c, const double* rin, double* zout) {
         ta.lv[l - lt] = TailLevel{L.n, L.nslice, X.n_coarse, L.ptr, L.col, X.agg, X.members, L.vals, L.dinv, L.x, L.x2, L.r};
     }
     ta.n_c = XL.n_coarse; ta.row0 = H.distributed ? H.offset : 0; ta.ncols = H.distributed ? H.n_glob : XL.n_coarse;
-    ta.inv = H.cinv; ta.cr = H.cr; ta.cx = H.cx; ta.cglob = H.distributed ? H.cglob : H.cr;
-    ta.omega = kAmgOmega; ta.alpha = H.alpha; ta.done = done;
+    ta.inv = H.cinv; ta.cr = H.cr; ta.cx = H.cx; ta.cglob = H.distributed ? H.cglob : nullptr;
+    ta.omega = w1; ta.omega2 = w2; ta.alpha = alpha; ta.done = done;
     ta.dense_in_tail = ta.ncols <= 128 ? 1 : 0;
     const int gemv_grid = std::min(2048, (ta.n_c + 3) / 4);
     if (H.distributed) {
@@ -421,8 +547,8 @@ hipError_t amg_vcycle(Ctx* c, const double* rin, double* zout) {
         if ((e = allreduce_buffer(c, H.cglob, H.cglob, (size_t)H.n_glob)) != hipSuccess) return e;
         PhaseTimer t(c, SHK_PH_AMG_COARSE);
         if (!ta.dense_in_tail)
-            hipLaunchKernelGGL(k_dense_gemv, dim3(gemv_grid), dim3(kBlock), 0, c->stream, ta.n_c, ta.row0, ta.ncols,
-                               ta.inv, ta.cglob, ta.cx, done);
+            hipLaunchKernelGGL(k_dense_gemv<double>, dim3(gemv_grid), dim3(kBlock), 0, c->stream, ta.n_c, ta.row0,
+                               ta.ncols, ta.inv, (const double*)H.cglob, ta.cx, done);
         hipLaunchKernelGGL(k_amg_tail<2>, dim3(1), dim3(kTailThreads), 0, c->stream, ta);
     } else if (ta.dense_in_tail) {
         PhaseTimer t(c, SHK_PH_AMG_COARSE);
@@ -430,45 +556,63 @@ hipError_t amg_vcycle(Ctx* c, const double* rin, double* zout) {
     } else {
         PhaseTimer t(c, SHK_PH_AMG_COARSE);
         if (ta.nlev > 0) hipLaunchKernelGGL(k_amg_tail<1>, dim3(1), dim3(kTailThreads), 0, c->stream, ta);
-        hipLaunchKernelGGL(k_dense_gemv, dim3(gemv_grid), dim3(kBlock), 0, c->stream, ta.n_c, ta.row0, ta.ncols, ta.inv,
-                           ta.cglob, ta.cx, done);
+        hipLaunchKernelGGL(k_dense_gemv<float>, dim3(gemv_grid), dim3(kBlock), 0, c->stream, ta.n_c, ta.row0, ta.ncols,
+                           ta.inv, (const float*)H.cr, ta.cx, done);
         hipLaunchKernelGGL(k_amg_tail<2>, dim3(1), dim3(kTailThreads), 0, c->stream, ta);
     }
     for (size_t l = lt; l-- > 0;) {
         const AmgXfer& X = H.xf[l];
-        const double* ec = X.dense ? H.cx : H.lv[l + 1].x2;
+        const float* ec = X.dense ? H.cx : H.lv[l + 1].x2;
         const bool fused = X.with_ap && !H.distributed;
-        if (!fused) {
-            PhaseTimer t(c, SHK_PH_AMG_COARSE);
-            hipLaunchKernelGGL(k_amg_prolong, dim3(small_grid(X.n_fine)), dim3(kBlock), 0, c->stream, X.n_fine, H.alpha,
-                               X.agg, ec, bufA(l), done);
-        }
-        AmgSmoothArgs a;
-        a.A = level_sell(c, H, l);
-        a.vals = vals(l); a.dinv = dinv(l); a.r = rhs(l);
-        a.rc = nullptr; a.members = nullptr; a.n_coarse = 0; a.omega = kAmgOmega; a.done = done;
-        const dim3 g(std::min((a.A.nslice + 3) / 4, 2048));
         const bool halo = H.distributed && (int)l < H.halo_levels;
-        if (fused) {
-            AmgFirstArgs f;
-            f.AP = DevSell{X.n_fine, X.n_coarse_cols, X.ap_nslice, sell_fits_cache(X.ap_slots), X.ap_ptr, X.ap_col,
-                           X.ap_rowlen, X.ap_cbase, X.ap_ptr16, X.ap_col16};
-            f.vals = X.ap_vals; f.dinv = dinv(l); f.r = rhs(l); f.e = ec; f.agg = X.agg; f.xo = bufB(l);
-            f.omega = kAmgOmega; f.alpha = H.alpha; f.done = done;
-            PhaseTimer t(c, l == 0 ? SHK_PH_AMG_FIRST : SHK_PH_AMG_COARSE);
-            if (l == 0) hipLaunchKernelGGL(k_amg_first<true>, g, dim3(kBlock), 0, c->stream, f);
-            else hipLaunchKernelGGL(k_amg_first<false>, g, dim3(kBlock), 0, c->stream, f);
-        }
-        for (int sweep = fused ? 1 : 0; sweep < 2; ++sweep) {
-            double* xin = sweep == 0 ? bufA(l) : bufB(l);
-            a.x = xin;
-            a.xo = sweep == 0 ? bufB(l) : bufA(l);
-            // distributed smoothing: the sweep needs the neighbours' current iterate on the ghost columns
-            // (without the exchange the ghost entries stay zero = block-local smoothing on that level)
-            if (halo && (e = halo_exchange_plan(c, c->comm.plans[H.plan_of[l]], xin)) != hipSuccess) return e;
-            PhaseTimer t(c, l == 0 ? SHK_PH_AMG_FINE : SHK_PH_AMG_COARSE);
-            if (l == 0) hipLaunchKernelGGL(k_amg_post<true>, g, dim3(kBlock), 0, c->stream, a);
-            else hipLaunchKernelGGL(k_amg_post<false>, g, dim3(kBlock), 0, c->stream, a);
+        const HaloPlan* HP = halo ? &c->comm.plans[H.plan_of[l]] : nullptr;
+        const DevSell A = level_sell(c, H, l);
+        const dim3 g(std::min((A.nslice + 3) / 4, 2048));
+        if (l == 0) {
+            // level 0: right-hand side = the Krylov vector, result = the preconditioned Krylov vector (both double),
+            // the iterate in between lives in the float scratch x0
+            if (fused) {
+                AmgFirstArgs<double> f{DevSell{X.n_fine, X.n_coarse_cols, X.ap_nslice, sell_fits_cache(X.ap_slots, kAmgSlotBytes),
+                                               X.ap_ptr, X.ap_col, X.ap_rowlen, X.ap_cbase, X.ap_ptr16, X.ap_col16},
+                                       X.ap_vals, c->d_dinv32, rin, ec, X.agg, H.x0, omega, alpha, done};
+                PhaseTimer t(c, SHK_PH_AMG_FIRST);
+                hipLaunchKernelGGL((k_amg_first<true, double>), g, dim3(kBlock), 0, c->stream, f);
+            } else {
+                {
+                    PhaseTimer t(c, SHK_PH_AMG_COARSE);
+                    hipLaunchKernelGGL(k_amg_prolong<double>, dim3(small_grid(X.n_fine)), dim3(kBlock), 0, c->stream,
+                                       X.n_fine, alpha, X.agg, ec, zout, done);
+                }
+                if (halo && (e = halo_exchange_plan(c, *HP, zout)) != hipSuccess) return e;
+                PhaseTimer t(c, SHK_PH_AMG_FINE);
+                launch_post<true>(c, A, c->d_vals32, c->d_dinv32, rin, (const double*)zout, H.x0, w1, done);
+            }
+            if (halo && (e = halo_exchange_plan_f32(c, *HP, H.x0)) != hipSuccess) return e;
+            PhaseTimer t(c, SHK_PH_AMG_FINE);
+            launch_post<true>(c, A, c->d_vals32, c->d_dinv32, rin, (const float*)H.x0, zout, w2, done);
+        } else {
+            const AmgLevel& L = H.lv[l];
+            if (fused) {
+                AmgFirstArgs<float> f{DevSell{X.n_fine, X.n_coarse_cols, X.ap_nslice, sell_fits_cache(X.ap_slots, kAmgSlotBytes),
+                                              X.ap_ptr, X.ap_col, X.ap_rowlen, X.ap_cbase, X.ap_ptr16, X.ap_col16},
+                                      X.ap_vals, L.dinv, L.r, ec, X.agg, L.x, omega, alpha, done};
+                PhaseTimer t(c, SHK_PH_AMG_COARSE);
+                hipLaunchKernelGGL((k_amg_first<false, float>), g, dim3(kBlock), 0, c->stream, f);
+            } else {
+                {
+                    PhaseTimer t(c, SHK_PH_AMG_COARSE);
+                    hipLaunchKernelGGL(k_amg_prolong<float>, dim3(small_grid(X.n_fine)), dim3(kBlock), 0, c->stream,
+                                       X.n_fine, alpha, X.agg, ec, L.x2, done);
+                }
+                // distributed smoothing: the sweep needs the neighbours' current iterate on the ghost columns
+                // (without the exchange the ghost entries stay zero = block-local smoothing on that level)
+                if (halo && (e = halo_exchange_plan_f32(c, *HP, L.x2)) != hipSuccess) return e;
+                PhaseTimer t(c, SHK_PH_AMG_COARSE);
+                launch_post<false>(c, A, L.vals, L.dinv, (const float*)L.r, (const float*)L.x2, L.x, w1, done);
+            }
+            if (halo && (e = halo_exchange_plan_f32(c, *HP, L.x)) != hipSuccess) return e;
+            PhaseTimer t(c, SHK_PH_AMG_COARSE);
+            launch_post<false>(c, A, L.vals, L.dinv, (const float*)L.r, (const float*)L.x, L.x2, w2, done);
         }
     }
     return hipSuccess;

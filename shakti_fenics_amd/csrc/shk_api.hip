@@ -138,10 +138,10 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
             if ((e = upload(c, &L.diag_slot, LP.diag_slot)) != hipSuccess) return e;
             const size_t nr = std::max<size_t>((size_t)L.nslice * kSlice, (size_t)L.n_cols);
             if ((e = dev_alloc(c, &L.vals, (size_t)L.slots)) != hipSuccess) return e;
-            double** vs[] = {&L.dinv, &L.x, &L.x2, &L.r};
-            for (double** v : vs) {
+            float** vs[] = {&L.dinv, &L.x, &L.x2, &L.r};
+            for (float** v : vs) {
                 if ((e = dev_alloc(c, v, nr)) != hipSuccess) return e;
-                if ((e = hipMemset(*v, 0, nr * sizeof(double))) != hipSuccess) return e;
+                if ((e = hipMemset(*v, 0, nr * sizeof(float))) != hipSuccess) return e;
             }
         } else {
             const size_t rows = H.distributed ? (size_t)H.n_glob : (size_t)LP.n_coarse;
@@ -158,7 +158,9 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
     if (const char* sa = getenv("SHK_AMG_ALPHA")) H.alpha = atof(sa);
     if (const char* sa = getenv("SHK_AMG_DENSE_PERIOD")) H.dense_period = std::max(1, atoi(sa));
     if ((e = dev_alloc(c, &H.x0, (size_t)n_loc0)) != hipSuccess) return e;
-    return hipMemset(H.x0, 0, (size_t)n_loc0 * sizeof(double));
+    if ((e = dev_alloc(c, &H.x1, (size_t)n_loc0)) != hipSuccess) return e;
+    if ((e = hipMemset(H.x1, 0, (size_t)n_loc0 * sizeof(float))) != hipSuccess) return e;
+    return hipMemset(H.x0, 0, (size_t)n_loc0 * sizeof(float));
 }
 }  // namespace shk
 
@@ -269,6 +271,9 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
     }
     if ((e = dev_alloc(c, &c->d_vals, (size_t)c->slots)) != hipSuccess) return bail(e, "alloc vals");
     if ((e = dev_alloc(c, &c->d_vals_s, (size_t)c->slots)) != hipSuccess) return bail(e, "alloc vals_s");
+    if ((e = dev_alloc(c, &c->d_vals32, (size_t)c->slots)) != hipSuccess) return bail(e, "alloc vals32");
+    if ((e = dev_alloc(c, &c->d_dinv32, nl)) != hipSuccess) return bail(e, "alloc dinv32");
+    if ((e = hipMemset(c->d_dinv32, 0, nl * sizeof(float))) != hipSuccess) return bail(e, "memset");
     if ((e = dev_alloc(c, &c->d_bcflag, nl)) != hipSuccess) return bail(e, "alloc bcflag");
     if ((e = hipMemset(c->d_bcflag, 0, nl)) != hipSuccess) return bail(e, "memset");
     if ((e = dev_alloc(c, &c->d_slotbc, (size_t)c->slots)) != hipSuccess) return bail(e, "alloc slotbc");
@@ -694,6 +699,7 @@ int shk_set_halo(shk_ctx* ctx, int32_t n_nbr, const int32_t* nbr_rank, const int
     }
     if (dev_alloc(c, &P.d_send_idx, (size_t)nsend) != hipSuccess) return fail("halo alloc");
     if (dev_alloc(c, &m.d_sendbuf, (size_t)nsend) != hipSuccess) return fail("halo alloc");
+    if (dev_alloc(c, &m.d_recvbuf, (size_t)nrecv) != hipSuccess) return fail("halo alloc");
     if (nsend > 0)
         HIPCHK(hipMemcpy(P.d_send_idx, P.h_send_idx.data(), (size_t)nsend * sizeof(int32_t), hipMemcpyHostToDevice));
     HIPCHK(hipHostMalloc((void**)&m.h_send, std::max<size_t>(1, (size_t)nsend) * sizeof(double)));

@@ -85,30 +85,29 @@ void comm_destroy(Ctx* c) {
     c->comm.kind = Comm::NONE;
 }
 
+template <class T>
 __global__ __launch_bounds__(kBlock) void k_pack(int64_t n, const int32_t* __restrict__ idx,
-                                                 const double* __restrict__ v, double* __restrict__ buf) {
+                                                 const T* __restrict__ v, double* __restrict__ buf) {
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
-        buf[i] = v[idx[i]];
+        buf[i] = (double)v[idx[i]];
+}
+__global__ __launch_bounds__(kBlock) void k_unpack_f32(int64_t n, const double* __restrict__ buf,
+                                                       float* __restrict__ ghost) {
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        ghost[i] = (float)buf[i];
 }
 
-// Fill the ghost segment of `vec` (a vector of the level that `P` belongs to) with the owners' current values.
-hipError_t halo_exchange_plan(Ctx* c, const HaloPlan& P, double* vec) {
+// Send the packed buffer, receive the neighbours' into `recv` (device memory, neighbour-major).
+static hipError_t exchange_packed(Ctx* c, const HaloPlan& P, double* recv) {
     Comm& m = c->comm;
-    if (m.kind == Comm::NONE || m.nranks <= 1 || P.nbr.empty()) return hipSuccess;
-    PhaseTimer t(c, SHK_PH_HALO);
     const int64_t nsend = P.send_ptr.back(), nrecv = P.recv_ptr.back();
-    if (nsend > 0) {
-        const int g = (int)std::min<int64_t>((nsend + kBlock - 1) / kBlock, 1024);
-        hipLaunchKernelGGL(k_pack, dim3(g), dim3(kBlock), 0, c->stream, nsend, P.d_send_idx, vec, m.d_sendbuf);
-    }
-    double* ghost = vec + P.n_own;
     if (m.kind == Comm::RCCL) {
         ncclComm_t comm = reinterpret_cast<ncclComm_t>(m.nccl);
         g_rccl.GroupStart();
         for (size_t k = 0; k < P.nbr.size(); ++k) {
             const int64_t ns = P.send_ptr[k + 1] - P.send_ptr[k], nr = P.recv_ptr[k + 1] - P.recv_ptr[k];
             if (ns > 0) g_rccl.Send(m.d_sendbuf + P.send_ptr[k], (size_t)ns, ncclDouble, P.nbr[k], comm, c->stream);
-            if (nr > 0) g_rccl.Recv(ghost + P.recv_ptr[k], (size_t)nr, ncclDouble, P.nbr[k], comm, c->stream);
+            if (nr > 0) g_rccl.Recv(recv + P.recv_ptr[k], (size_t)nr, ncclDouble, P.nbr[k], comm, c->stream);
         }
         ncclResult_t r = g_rccl.GroupEnd();
         return r == ncclSuccess ? hipSuccess : hipErrorUnknown;
@@ -124,8 +123,41 @@ hipError_t halo_exchange_plan(Ctx* c, const HaloPlan& P, double* vec) {
                       P.recv_ptr.data()) != 0)
         return hipErrorUnknown;
     if (nrecv > 0)
-        e = hipMemcpyAsync(ghost, m.h_recv, (size_t)nrecv * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        e = hipMemcpyAsync(recv, m.h_recv, (size_t)nrecv * sizeof(double), hipMemcpyHostToDevice, c->stream);
     return e;
+}
+
+// Fill the ghost segment of `vec` (a vector of the level that `P` belongs to) with the owners' current values.
+hipError_t halo_exchange_plan(Ctx* c, const HaloPlan& P, double* vec) {
+    Comm& m = c->comm;
+    if (m.kind == Comm::NONE || m.nranks <= 1 || P.nbr.empty()) return hipSuccess;
+    PhaseTimer t(c, SHK_PH_HALO);
+    const int64_t nsend = P.send_ptr.back();
+    if (nsend > 0) {
+        const int g = (int)std::min<int64_t>((nsend + kBlock - 1) / kBlock, 1024);
+        hipLaunchKernelGGL(k_pack<double>, dim3(g), dim3(kBlock), 0, c->stream, nsend, P.d_send_idx, vec, m.d_sendbuf);
+    }
+    return exchange_packed(c, P, vec + P.n_own);
+}
+
+// The same for a float vector of the multigrid preconditioner: values travel as doubles (the volume is a few
+// thousand entries) and are narrowed again on arrival.
+hipError_t halo_exchange_plan_f32(Ctx* c, const HaloPlan& P, float* vec) {
+    Comm& m = c->comm;
+    if (m.kind == Comm::NONE || m.nranks <= 1 || P.nbr.empty()) return hipSuccess;
+    PhaseTimer t(c, SHK_PH_HALO);
+    const int64_t nsend = P.send_ptr.back(), nrecv = P.recv_ptr.back();
+    if (nsend > 0) {
+        const int g = (int)std::min<int64_t>((nsend + kBlock - 1) / kBlock, 1024);
+        hipLaunchKernelGGL(k_pack<float>, dim3(g), dim3(kBlock), 0, c->stream, nsend, P.d_send_idx, vec, m.d_sendbuf);
+    }
+    hipError_t e = exchange_packed(c, P, m.d_recvbuf);
+    if (e != hipSuccess) return e;
+    if (nrecv > 0) {
+        const int g = (int)std::min<int64_t>((nrecv + kBlock - 1) / kBlock, 1024);
+        hipLaunchKernelGGL(k_unpack_f32, dim3(g), dim3(kBlock), 0, c->stream, nrecv, m.d_recvbuf, vec + P.n_own);
+    }
+    return hipSuccess;
 }
 
 hipError_t halo_exchange(Ctx* c, double* vec) {

@@ -74,17 +74,20 @@ template <bool NT, class T>
 __device__ __forceinline__ T sell_ld(const T* p) {
     return NT ? __builtin_nontemporal_load(p) : *p;
 }
-template <bool NT>
-__device__ __forceinline__ double sell_row_sum_t(const DevSell& A, const double* __restrict__ vals,
-                                                 const double* __restrict__ x, int s, int lane) {
+// TV / TX: value and vector element types (double for the Krylov operator; the multigrid preconditioner stores
+// its operators and vectors in float, see shk_amg.hip).  The sum is accumulated in their common type.
+template <bool NT, class TV, class TX>
+__device__ __forceinline__ auto sell_row_sum_t(const DevSell& A, const TV* __restrict__ vals,
+                                               const TX* __restrict__ x, int s, int lane) -> decltype(TV() * TX()) {
+    using TA = decltype(TV() * TX());
     const int base = __builtin_amdgcn_readfirstlane(A.ptr[s]);
     const int width = (__builtin_amdgcn_readfirstlane(A.ptr[s + 1]) - base) >> 6;
     const int cb = __builtin_amdgcn_readfirstlane(A.cbase[s]);
-    const double* __restrict__ vp = vals + base + lane;
-    double sum = 0.0;
+    const TV* __restrict__ vp = vals + base + lane;
+    TA sum = 0;
     if (cb >= 0) {
         const uint16_t* __restrict__ cp = A.col16 + __builtin_amdgcn_readfirstlane(A.ptr16[s]) + lane;
-        const double* __restrict__ xb = x + cb;
+        const TX* __restrict__ xb = x + cb;
 #pragma unroll 4
         for (int k = 0; k < width; ++k) sum += sell_ld<NT>(vp + k * kSlice) * xb[sell_ld<NT>(cp + k * kSlice)];
     } else {
@@ -94,8 +97,9 @@ __device__ __forceinline__ double sell_row_sum_t(const DevSell& A, const double*
     }
     return sum;
 }
-__device__ __forceinline__ double sell_row_sum(const DevSell& A, const double* __restrict__ vals,
-                                               const double* __restrict__ x, int s, int lane) {
+template <class TV, class TX>
+__device__ __forceinline__ auto sell_row_sum(const DevSell& A, const TV* __restrict__ vals,
+                                             const TX* __restrict__ x, int s, int lane) -> decltype(TV() * TX()) {
     return A.xcd_local ? sell_row_sum_t<false>(A, vals, x, s, lane) : sell_row_sum_t<true>(A, vals, x, s, lane);
 }
 
@@ -122,11 +126,12 @@ struct AsmArgs {
     QuadArg qpoly;           // degree-5 rule (7 points): every polynomial term (quad again if n != 3)
 };
 
-inline int32_t sell_fits_cache(int64_t slots) {
+inline int32_t sell_fits_cache(int64_t slots, int bytes_per_slot = 12) {   // 8 B value + 4 B column
     static const int force = getenv("SHK_XCD") ? atoi(getenv("SHK_XCD")) : -1;  // experiment switch: 0 / 1 / 2
     if (force >= 0) return force;
-    return slots * 12 < (int64_t)192 << 20 ? 1 : 0;
+    return slots * bytes_per_slot < (int64_t)192 << 20 ? 1 : 0;
 }
+constexpr int kAmgSlotBytes = 8;   // float value + (mostly 16-bit) column
 
 // Multigrid hierarchy on the device (shk_amg.hip).  Level 0 is the Jacobian itself (Ctx::d_vals, d_dinv).
 struct AmgLevel {
@@ -135,7 +140,7 @@ struct AmgLevel {
     int32_t *ptr = nullptr, *col = nullptr, *diag_slot = nullptr, *cbase = nullptr, *ptr16 = nullptr;
     uint16_t* col16 = nullptr;
     uint8_t* rowlen = nullptr;
-    double *vals = nullptr, *dinv = nullptr, *x = nullptr, *x2 = nullptr, *r = nullptr;
+    float *vals = nullptr, *dinv = nullptr, *x = nullptr, *x2 = nullptr, *r = nullptr;   // preconditioner precision
 };
 struct AmgXfer {  // level l -> l+1
     int32_t n_fine = 0, n_coarse = 0, n_coarse_cols = 0;
@@ -149,7 +154,7 @@ struct AmgXfer {  // level l -> l+1
             *ap_glist = nullptr;
     uint16_t* ap_col16 = nullptr;
     uint8_t* ap_rowlen = nullptr;
-    double* ap_vals = nullptr;
+    float* ap_vals = nullptr;
 };
 // A hierarchy is either block-local (the owned diagonal block of a subdomain, or the whole matrix of a single
 // context: no communication) or distributed (ghost columns kept on every level, per-level halo plans, one
@@ -159,18 +164,26 @@ struct AmgHierarchy {
     std::vector<AmgXfer> xf;     // [l] : level l -> l+1; the last one lands on the dense coarsest level
     std::vector<int> plan_of;    // distributed: index into Comm::plans of level l's halo plan (size = xf.size())
     bool distributed = false;
-    double alpha = 1.4;          // over-correction x = alpha * P e_c: piecewise-constant prolongation under-estimates
+    double alpha = 1.5;          // over-correction x = alpha * P e_c: piecewise-constant prolongation under-estimates
                                  // the coarse correction.  Measured ms/step at 10M | 1M rows: alpha 1.0: 870 | 108,
-                                 // 1.3: 641 | 81, 1.5: 646 | 81, 1.7: 703 | 80, 2.0: 899 | 92   (SHK_AMG_ALPHA)
+                                 // 1.3: 641 | 81, 1.5: 646 | 81, 1.7: 703 | 80, 2.0: 899 | 92; with the float cycle and the
+                                 // (1.0, 0.6) sweeps: 1.4: 282 | 52, 1.5: 274 | 49, 1.6: 268 | 49   (SHK_AMG_ALPHA)
     bool dense_valid = false;    // the dense coarsest inverse has been built at least once
     int dense_age = 0, dense_period = 8;   // Newton solves since / between rebuilds of a big inverse (SHK_AMG_DENSE_PERIOD)
     int its_fresh = 0, its_last = 0;       // Krylov iterations of the first solve after a rebuild / of the last solve
     int halo_levels = 2;         // levels [0, halo_levels) exchange ghosts inside the smoother (SHK_AMG_HALO_LEVELS);
                                  // measured at 1M rows / 4 subdomains: 0 -> 195, 1 -> 144, 2 -> 134, 3 -> 125,
                                  // all -> 110 BiCGStab iterations per Newton step (one subdomain: 138)
+    // Two damped-Jacobi sweeps x <- x + (c_k / lambda) D^-1 (r - A x), lambda ~ the largest eigenvalue of D^-1 A
+    // over the levels (power iteration at the rebuilds of the dense inverse, +10 % because it converges from
+    // below).  c = (2.35, 1.41) is the pair measured best on the 10M-row system (lambda there = 2.35: w = 1.0,
+    // 0.6; 61 iterations per Newton step against 69 for 0.7, 0.7 -- and 0.9, 0.9 diverges).  (SHK_AMG_W1/W2)
+    double lambda = 0.0;             // 0: not estimated yet
+    double c1 = 2.35, c2 = 1.41;
     int64_t ap_nnz0 = 0;             // stored entries of the finest level's A*P operator
     int32_t n_glob = 0, offset = 0;  // dense coarsest operator: n_glob x n_glob, my rows start at `offset`
-    double *x0 = nullptr, *cdense = nullptr, *cinv = nullptr, *cr = nullptr, *cx = nullptr, *cglob = nullptr;
+    float *x0 = nullptr, *x1 = nullptr, *cr = nullptr, *cx = nullptr;   // x1: power-iteration scratch (finest level)
+    double *cdense = nullptr, *cinv = nullptr, *cglob = nullptr;   // the coarsest solve stays in double
     double* gj = nullptr;        // 2 * 1024 doubles of Gauss-Jordan scratch
     bool ready() const { return !xf.empty(); }
 };
@@ -194,6 +207,7 @@ struct Comm {
     void* cb_user = nullptr;
     std::vector<HaloPlan> plans;             // [0] fine level, [l] multigrid level l (distributed hierarchy)
     double* d_sendbuf = nullptr;             // sized for plans[0], the largest
+    double* d_recvbuf = nullptr;             // staging of a float vector's ghosts (they travel as doubles)
     double *h_send = nullptr, *h_recv = nullptr, *h_red = nullptr;  // pinned staging (CALLBACK)
     size_t h_red_cap = 0;
 };
@@ -232,6 +246,7 @@ struct Ctx {
     int64_t cells_staged = 0;  // cells computed per assembly incl. those shared between blocks
     size_t asm_lds = 0;
     double *d_F = nullptr, *d_vals = nullptr, *d_vals_s = nullptr, *d_dinv = nullptr;
+    float *d_vals32 = nullptr, *d_dinv32 = nullptr;   // float copies read by the multigrid preconditioner
     // Krylov vectors
     double *d_r = nullptr, *d_rhat = nullptr, *d_p = nullptr, *d_v = nullptr, *d_s = nullptr, *d_t = nullptr,
            *d_y = nullptr, *d_ytot = nullptr, *d_rhs = nullptr;
@@ -259,6 +274,11 @@ struct Ctx {
     DevSell sell() const {
         return DevSell{(int32_t)n_own, (int32_t)n_loc, plan.A.nslice, sell_fits_cache(slots), d_sell_ptr, d_sell_col,
                        d_rowlen, d_cbase, d_ptr16, d_col16};
+    }
+    DevSell sell32() const {   // same pattern, cache rule of the float copy
+        DevSell A = sell();
+        A.xcd_local = sell_fits_cache(slots, kAmgSlotBytes);
+        return A;
     }
 };
 
@@ -310,6 +330,7 @@ const char* rccl_init(Ctx* c, int rank, int nranks, const void* id128);
 void comm_destroy(Ctx* c);
 hipError_t halo_exchange(Ctx* c, double* vec);                       // level 0
 hipError_t halo_exchange_plan(Ctx* c, const HaloPlan& P, double* vec);
+hipError_t halo_exchange_plan_f32(Ctx* c, const HaloPlan& P, float* vec);
 hipError_t allreduce_buffer(Ctx* c, const double* src, double* dst, size_t n);  // element-wise sum over subdomains
 int amg_setup_distributed(Ctx* c, std::string& err);  // collective
 hipError_t amg_numeric_setup(Ctx* c, bool refresh_dense);

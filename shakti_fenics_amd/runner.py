@@ -92,7 +92,8 @@ class SingleRunner:
         nv, nnz, slices = self.nv_global, self.nnz_global, (self.nv_global + 63) // 64
         # algorithmic bytes per launch (fp64 values, int32 indices), SURVEY.md 8d
         b_spmv = 12 * nnz + 4 * (nv + 1) + 16 * nv                      # values, colidx, rowptr, x, y = 104 nv
-        b_post = 12 * nnz + 4 * (slices + 1) + 32 * nv                  # + r, 1/diag: x' = x + w D^-1 (r - A x)
+        # multigrid smoother: float values + int32 indices; x (float), r (double), 1/diag (float), x' (double)
+        b_post = 8 * nnz + 4 * (slices + 1) + 24 * nv                   # x' = x + w D^-1 (r - A x)
         b_asm = 12 * self.ne_global + 16 * nv + 88 * nv + 8 * nv + 8 * nnz  # 192 nv
 
         pmc = _pmc_traffic(getattr(self, "config_name", None), nv)
@@ -111,7 +112,7 @@ class SingleRunner:
             legs["amg_fine"] = leg("amg_fine", b_post, "k_amg_post<true> (finest-level multigrid smoother, SELL-64 SpMV)")
         if prof.get("amg_first", {}).get("launches"):
             ap = c.plan_stats()["ap_nnz"]
-            b_first = 12 * ap + 4 * (slices + 1) + 4 * nv + 24 * nv + 2 * nv   # A*P, agg, r / 1/diag / x', e
+            b_first = 8 * ap + 4 * (slices + 1) + 4 * nv + 16 * nv + 1 * nv    # A*P (float), agg, r / 1/diag / x', e
             legs["amg_first"] = leg("amg_first", b_first, "k_amg_first<true> (first sweep on the A*P operator)")
         dom = max((k for k in legs if k != "assemble"), key=lambda k: prof[k]["ms"])
         d = legs[dom]
