@@ -104,6 +104,7 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
     const size_t nx = plans.size();
     H.xf.resize(nx);
     H.lv.resize(nx);  // [0] unused; sparse levels 1 .. nx-1
+    std::vector<int32_t> prev_pos, prev_rank;
     for (size_t l = 0; l < nx; ++l) {
         AmgLevelPlan& LP = plans[l];
         AmgXfer& X = H.xf[l];
@@ -112,6 +113,37 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
         if ((e = upload(c, &X.members, LP.members)) != hipSuccess) return e;
         if ((e = upload(c, &X.gptr, LP.gptr)) != hipSuccess) return e;
         if ((e = upload(c, &X.glist, LP.glist)) != hipSuccess) return e;
+        if (l < (size_t)kFusedRestrict) {
+            // tables of the fused restriction, indexed by k-d rank; they rely on rank k's members sitting in the
+            // 256-row group k / 64 of the finer level (true for every hierarchy built here; checked anyway)
+            const int32_t nc = LP.n_coarse;
+            std::vector<int32_t> mk((size_t)4 * nc), pos(nc);
+            bool ok = LP.kd_pos.empty() || (int32_t)LP.kd_pos.size() == nc;
+            for (int32_t k = 0; ok && k < nc; ++k) {
+                const int32_t I = LP.kd_pos.empty() ? k : LP.kd_pos[k];
+                if (I < 0 || I >= nc) { ok = false; break; }
+                pos[k] = I;
+                for (int q = 0; q < 4; ++q) {
+                    const int32_t m = LP.members[(size_t)4 * I + q];
+                    mk[(size_t)4 * k + q] = m;
+                    if (q == 0 && m < 0) ok = false;
+                    if (m < 0) continue;
+                    if (m / 256 != k / 64) ok = false;
+                    // ... and the member's own k-d rank must be one of 4k .. 4k+3
+                    const int32_t mr = l == 0 ? ((size_t)m < c->plan.krank.size() ? c->plan.krank[m] : -1)
+                                              : (prev_pos.empty() ? m : prev_rank[m]);
+                    if (mr / 4 != k) ok = false;
+                }
+            }
+            // k-d rank of every row of the level just described (= the finer level of the next transfer)
+            prev_pos = LP.kd_pos;
+            prev_rank.assign(prev_pos.size(), -1);
+            for (size_t k = 0; k < prev_pos.size(); ++k) prev_rank[prev_pos[k]] = (int32_t)k;
+            if (ok) {
+                if ((e = upload(c, &X.members_kd, mk)) != hipSuccess) return e;
+                if ((e = upload(c, &X.kd_pos, pos)) != hipSuccess) return e;
+            }
+        }
         if (LP.with_ap) {
             X.with_ap = true; X.ap_nslice = LP.AP.nslice; X.ap_slots = LP.AP.slots;
             if (l == 0) H.ap_nnz0 = LP.AP.nnz;

@@ -76,31 +76,127 @@ __device__ __forceinline__ T sell_ld(const T* p) {
 }
 // TV / TX: value and vector element types (double for the Krylov operator; the multigrid preconditioner stores
 // its operators and vectors in float, see shk_amg.hip).  The sum is accumulated in their common type.
-template <bool NT, class TV, class TX>
+// A slice is 4 .. 11 entries wide.  A loop (even unrolled by 4, with its one-at-a-time remainder) would chain
+// a load -> gather round trip per trip; instead the width, which is wave-uniform, selects a fully unrolled
+// body that issues all value/column loads of the slice, then all gathers, then the FMAs in slot order
+// (measured on MI355X, 10M rows, hipEvent legs: k_spmv 224 -> 205 us, k_amg_first<true> 137 -> 119 us).
+template <bool NT, int W, class TV, class TC, class TX>
+__device__ __forceinline__ auto sell_fixed(const TV* __restrict__ vp, const TC* __restrict__ cp,
+                                           const TX* __restrict__ xb) -> decltype(TV() * TX()) {
+    TV v[W];
+    TC c[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) { v[k] = sell_ld<NT>(vp + k * kSlice); c[k] = sell_ld<NT>(cp + k * kSlice); }
+    decltype(TV() * TX()) sum = 0;
+#pragma unroll
+    for (int k = 0; k < W; ++k) sum += v[k] * xb[c[k]];
+    return sum;
+}
+template <bool NT, int WMAX, class TV, class TC, class TX>
+__device__ __forceinline__ auto sell_width(const TV* __restrict__ vp, const TC* __restrict__ cp,
+                                           const TX* __restrict__ xb, int width) -> decltype(TV() * TX()) {
+    decltype(TV() * TX()) sum = 0;
+    while (width > WMAX) {
+        sum += sell_fixed<NT, WMAX>(vp, cp, xb);
+        vp += WMAX * kSlice; cp += WMAX * kSlice; width -= WMAX;
+    }
+    switch (width) {
+        case 1: return sum + sell_fixed<NT, 1>(vp, cp, xb);
+        case 2: return sum + sell_fixed<NT, 2>(vp, cp, xb);
+        case 3: return sum + sell_fixed<NT, 3>(vp, cp, xb);
+        case 4: return sum + sell_fixed<NT, 4>(vp, cp, xb);
+        case 5: return sum + sell_fixed<NT, 5>(vp, cp, xb);
+        case 6: return sum + sell_fixed<NT, 6>(vp, cp, xb);
+        case 7: return sum + sell_fixed<NT, 7>(vp, cp, xb);
+        case 8: return sum + sell_fixed<NT, 8>(vp, cp, xb);
+        case 9: if (WMAX >= 9) return sum + sell_fixed<NT, 9>(vp, cp, xb);
+        case 10: if (WMAX >= 10) return sum + sell_fixed<NT, 10>(vp, cp, xb);
+        case 11: if (WMAX >= 11) return sum + sell_fixed<NT, 11>(vp, cp, xb);
+        case 12: if (WMAX >= 12) return sum + sell_fixed<NT, 12>(vp, cp, xb);
+        default: return sum;
+    }
+}
+template <bool NT, int WMAX, class TV, class TX>
 __device__ __forceinline__ auto sell_row_sum_t(const DevSell& A, const TV* __restrict__ vals,
                                                const TX* __restrict__ x, int s, int lane) -> decltype(TV() * TX()) {
-    using TA = decltype(TV() * TX());
     const int base = __builtin_amdgcn_readfirstlane(A.ptr[s]);
     const int width = (__builtin_amdgcn_readfirstlane(A.ptr[s + 1]) - base) >> 6;
     const int cb = __builtin_amdgcn_readfirstlane(A.cbase[s]);
     const TV* __restrict__ vp = vals + base + lane;
-    TA sum = 0;
-    if (cb >= 0) {
-        const uint16_t* __restrict__ cp = A.col16 + __builtin_amdgcn_readfirstlane(A.ptr16[s]) + lane;
-        const TX* __restrict__ xb = x + cb;
-#pragma unroll 4
-        for (int k = 0; k < width; ++k) sum += sell_ld<NT>(vp + k * kSlice) * xb[sell_ld<NT>(cp + k * kSlice)];
-    } else {
-        const int32_t* __restrict__ cp = A.col + base + lane;
-#pragma unroll 4
-        for (int k = 0; k < width; ++k) sum += sell_ld<NT>(vp + k * kSlice) * x[sell_ld<NT>(cp + k * kSlice)];
-    }
-    return sum;
+    if (cb >= 0)
+        return sell_width<NT, WMAX>(vp, A.col16 + __builtin_amdgcn_readfirstlane(A.ptr16[s]) + lane, x + cb, width);
+    return sell_width<NT, WMAX>(vp, A.col + base + lane, x, width);
 }
-template <class TV, class TX>
+// WMAX = 8 or 12: widest fully unrolled body (registers against round trips; 12 pays for the double-precision
+// Krylov product, whose slices are up to 11 wide, 8 for the float smoothers)
+template <int WMAX = 8, class TV, class TX>
 __device__ __forceinline__ auto sell_row_sum(const DevSell& A, const TV* __restrict__ vals,
                                              const TX* __restrict__ x, int s, int lane) -> decltype(TV() * TX()) {
-    return A.xcd_local ? sell_row_sum_t<false>(A, vals, x, s, lane) : sell_row_sum_t<true>(A, vals, x, s, lane);
+    return A.xcd_local ? sell_row_sum_t<false, WMAX>(A, vals, x, s, lane) : sell_row_sum_t<true, WMAX>(A, vals, x, s, lane);
+}
+
+// Multigrid down-sweep over four levels in one launch (k_amg_restrict4).  An aligned group of 256 rows holds
+// complete aggregate trees four levels deep (256 = 4^4): one workgroup pass leaves the right-hand sides of
+// levels 1 .. nlev behind, through LDS, instead of one launch per level.  Tables are indexed by the coarse row's
+// k-d rank, which is what a workgroup can enumerate: group g owns ranks [g 4^(4-l), (g+1) 4^(4-l)) of level l.
+// (Fusing this into k_bicg_s / k_bicg_u, which produce the vectors, was measured slower: the barriers stall
+// their load streams -- vector phase 25 -> 51 ms per step at 10M rows for 8 ms saved here.)
+constexpr int kFusedRestrict = 4;
+struct RestrictArgs {
+    int nlev;                              // 0: off
+    const int4* members[kFusedRestrict];   // [l][k]: the (<= 4, -1 padded) rows of level l under rank k of level l+1
+    const int32_t* pos[kFusedRestrict];    // [l][k]: storage position of rank k of level l+1
+    float* rc[kFusedRestrict];             // right-hand side of level l+1
+    int32_t nc[kFusedRestrict];            // rows of level l+1
+};
+// All 256 threads call this once per group g with their entry of the vector (0 beyond the end).  Threads 0..63
+// produce the group's level-1 rows, 64..79 its level-2 rows, 80..83 level 3, 84 level 4; every role fetches its
+// table entries up front (one memory round trip per group), the sums then cascade through LDS.  Sums run in the
+// member order of k_amg_restrict, so both paths give the same bits.
+__device__ __forceinline__ void fused_restrict(const RestrictArgs& ra, int g, double val, double* buf0,
+                                               float (*buf)[256]) {
+    const int tid = threadIdx.x;
+    const int lvl = tid < 64 ? 0 : tid < 80 ? 1 : tid < 84 ? 2 : tid == 84 ? 3 : -1;
+    const int j = tid < 64 ? tid : tid < 80 ? tid - 64 : tid < 84 ? tid - 80 : 0;
+    bool act = lvl >= 0 && lvl < ra.nlev;
+    int4 m = make_int4(-1, -1, -1, -1);
+    int p = 0;
+    float* rc = nullptr;
+    if (act) {
+        const int k = g * (64 >> (2 * lvl)) + j;
+        const int4* mt = lvl == 0 ? ra.members[0] : lvl == 1 ? ra.members[1] : lvl == 2 ? ra.members[2] : ra.members[3];
+        const int32_t* pt = lvl == 0 ? ra.pos[0] : lvl == 1 ? ra.pos[1] : lvl == 2 ? ra.pos[2] : ra.pos[3];
+        const int32_t nc = lvl == 0 ? ra.nc[0] : lvl == 1 ? ra.nc[1] : lvl == 2 ? ra.nc[2] : ra.nc[3];
+        rc = lvl == 0 ? ra.rc[0] : lvl == 1 ? ra.rc[1] : lvl == 2 ? ra.rc[2] : ra.rc[3];
+        act = k < nc;
+        if (act) { m = mt[k]; p = pt[k]; }
+    }
+    __syncthreads();   // the previous group's readers are done
+    buf0[tid] = val;
+    __syncthreads();
+    if (act && lvl == 0) {
+        const int b0 = g << 8;
+        double acc = buf0[m.x - b0];
+        if (m.y >= 0) acc += buf0[m.y - b0];
+        if (m.z >= 0) acc += buf0[m.z - b0];
+        if (m.w >= 0) acc += buf0[m.w - b0];
+        const float rv = (float)acc;
+        rc[p] = rv;
+        buf[0][p & 255] = rv;
+    }
+#pragma unroll
+    for (int l = 1; l < kFusedRestrict; ++l) {
+        if (l >= ra.nlev) break;
+        __syncthreads();
+        if (act && lvl == l) {
+            float acc = buf[l - 1][m.x & 255];
+            if (m.y >= 0) acc += buf[l - 1][m.y & 255];
+            if (m.z >= 0) acc += buf[l - 1][m.z & 255];
+            if (m.w >= 0) acc += buf[l - 1][m.w & 255];
+            rc[p] = acc;
+            if (l + 1 < kFusedRestrict) buf[l][p & 255] = acc;
+        }
+    }
 }
 
 struct AsmArgs {
@@ -145,6 +241,7 @@ struct AmgLevel {
 struct AmgXfer {  // level l -> l+1
     int32_t n_fine = 0, n_coarse = 0, n_coarse_cols = 0;
     int32_t *agg = nullptr, *members = nullptr, *gptr = nullptr, *glist = nullptr;
+    int32_t *members_kd = nullptr, *kd_pos = nullptr;   // fused restriction tables (RestrictArgs); null: unavailable
     bool dense = false;
     // A*P of the fine level (optional): thinner operator for the first smoothing sweep after the prolongation
     bool with_ap = false;
@@ -289,6 +386,8 @@ struct Ctx {
 struct GroupSweep {
     int begin, end, step;
 };
+// (Dealing chunks of 4 .. 1024 consecutive groups to the XCDs in turn -- close streams, still XCD-local runs --
+// measured the same as plain round robin at 10M rows: the x vector is served by the Infinity Cache either way.)
 __device__ __forceinline__ GroupSweep xcd_sweep(int ngroups, int xcd_local) {
     const int nb = gridDim.x, b = blockIdx.x;
     if (!xcd_local || (nb & 7) != 0) return GroupSweep{b, ngroups, nb};

@@ -334,7 +334,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const SpmvArgs a) {
     for (int g = sw.begin; g < sw.end; g += sw.step) {
         const int s = 4 * g + wave;
         if (s >= a.A.nslice) break;
-        const double sum = sell_row_sum(a.A, a.vals, a.x, s, lane);
+        const double sum = sell_row_sum<12>(a.A, a.vals, a.x, s, lane);
         const int row = s * kSlice + lane;
         if (row < a.A.n_rows) {
             a.y[row] = sum;

@@ -522,7 +522,9 @@ static std::string coarsen_sorted(const SellPattern& Af, const std::vector<int32
     std::vector<int32_t> agg2(agg.size()), colmap2(colmap.size());
     for (size_t i = 0; i < agg.size(); ++i) agg2[i] = inv[agg[i]];
     for (size_t c = 0; c < colmap.size(); ++c) colmap2[c] = colmap[c] >= 0 ? inv[colmap[c]] : -1;
-    return coarsen(Af, agg2, colmap2, n_coarse, n_coarse, false, L);
+    std::string err = coarsen(Af, agg2, colmap2, n_coarse, n_coarse, false, L);
+    L.kd_pos = inv;
+    return err;
 }
 
 // Block-local hierarchy of the owned diagonal block (ghost columns dropped): needs no communication.

@@ -55,6 +55,7 @@ struct AmgLevelPlan {
     std::vector<int32_t> gptr;      // coarse slots+1 (or n_coarse^2+1 when dense) into glist
     std::vector<int32_t> glist;     // fine slots summed into each coarse slot, ascending
     std::vector<int32_t> diag_slot; // n_coarse        : slot of the coarse diagonal (sparse levels)
+    std::vector<int32_t> kd_pos;    // n_coarse : coarse row (storage position) of k-d rank k; empty = identity
     bool dense = false;
     // A*P (fine rows x coarse columns, ~4 entries per row instead of ~7): lets the first smoothing sweep after
     // the prolongation read a thinner operator and skip the prolongated vector altogether:
