@@ -176,6 +176,23 @@ int shk_time_kernel(shk_ctx* ctx, int32_t phase, int32_t reps, double dt, double
  * n[9]=multigrid levels (sparse + dense) n[10]=rows of the dense coarsest level n[11]=reserved */
 int shk_plan_stats(shk_ctx* ctx, int64_t n[12]);
 
+/* ---- setup-time data ingestion (context-free: host arrays in and out, caller's node order) ----
+ * Bilinear interpolation of gridded data to npts points: replaces the RegularGridInterpolator evaluation of
+ * model_setup.interp_data (/root/reference/source/model_setup.py:84-86; linear, bounds_error=False,
+ * fill_value=None -> points outside the grid extrapolate from the edge cell).  xg (nx) and yg (ny) strictly
+ * ascending; f_xy is (nx, ny) row-major, f_xy[ix*ny + iy] -- the transposed array the reference passes to scipy.
+ * Bit-identical to scipy's result: pairwise_weights = 0 rounds like scipy's 2-D float64 fast path,
+ * (f*wx)*wy, which is what float64 data gets; 1 like its generic evaluator, f*(wx*wy), used for float32 or
+ * read-only data. */
+int shk_interp_regular_grid(int device_id, int64_t npts, const double* px, const double* py, int64_t nx, int64_t ny,
+                            const double* xg, const double* yg, const double* f_xy, int32_t pairwise_weights,
+                            double* out);
+/* out[p] = 1.0 if point p lies inside the polygon poly_xy (m vertices, x0,y0,x1,y1,..., closed implicitly), else
+ * 0.0, by the even-odd rule: replaces the per-node shapely loop of model_setup.set_lake_bdry
+ * (model_setup.py:68-72). */
+int shk_points_in_polygon(int device_id, int64_t npts, const double* px, const double* py, int64_t m,
+                          const double* poly_xy, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,7 +48,8 @@ EXPORTS = (
     "shk_assemble", "shk_get_residual", "shk_csr_nnz", "shk_get_csr", "shk_linear_solve", "shk_spmv",
     "shk_newton_solve", "shk_update_explicit", "shk_step", "shk_sync", "shk_profile_enable",
     "shk_profile_read", "shk_time_kernel", "shk_plan_stats", "shk_set_halo", "shk_comm_unique_id",
-    "shk_comm_init_rccl", "shk_comm_init_callbacks", "shk_halo_update",
+    "shk_comm_init_rccl", "shk_comm_init_callbacks", "shk_halo_update", "shk_interp_regular_grid",
+    "shk_points_in_polygon",
 )
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double),
@@ -102,6 +103,8 @@ def load():
         "shk_comm_init_rccl": ([vp, i32, i32, vp], C.c_int),
         "shk_comm_init_callbacks": ([vp, i32, i32, EXCHANGE_FN, ALLREDUCE_FN, vp], C.c_int),
         "shk_halo_update": ([vp, i32], C.c_int),
+        "shk_interp_regular_grid": ([C.c_int, i64, vp, vp, i64, i64, vp, vp, vp, i32, vp], C.c_int),
+        "shk_points_in_polygon": ([C.c_int, i64, vp, vp, i64, vp, vp], C.c_int),
     }
     for name, (args, res) in sig.items():
         fn = getattr(lib, name)
@@ -121,6 +124,57 @@ def rccl_unique_id() -> bytes:
 
 def _ptr(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def interp_regular_grid(px, py, xg, yg, f_xy, device: int = 0) -> np.ndarray:
+    """Bilinear interpolation (with edge-cell extrapolation) of f_xy[ix, iy] given on the rectilinear grid
+    xg x yg to the points (px, py), on the GPU -- the evaluation
+    `RegularGridInterpolator((xg, yg), f_xy, bounds_error=False, fill_value=None)(points)` of
+    /root/reference/source/model_setup.py:84-86, bit for bit.  Axes may ascend or descend (scipy flips
+    descending axes; so does this wrapper).  scipy rounds float64 data through its 2-D fast path and anything
+    else (float32, read-only arrays) through a generic evaluator that associates the weights differently; the
+    same rule picks the kernel's variant here."""
+    px = np.ascontiguousarray(px, dtype=np.float64).ravel()
+    py = np.ascontiguousarray(py, dtype=np.float64).ravel()
+    xg = np.asarray(xg, dtype=np.float64).ravel()
+    yg = np.asarray(yg, dtype=np.float64).ravel()
+    f_in = np.asarray(f_xy)
+    if not np.issubdtype(f_in.dtype, np.inexact):
+        f_in = f_in.astype(float)          # what RegularGridInterpolator.__init__ does with integer data
+    fast_path = f_in.ndim == 2 and f_in.flags.writeable and f_in.dtype == np.float64 and f_in.dtype.byteorder == "="
+    f = np.asarray(f_in, dtype=np.float64)
+    if px.shape != py.shape:
+        raise ValueError("px and py differ in length")
+    if f.shape != (xg.size, yg.size):
+        raise ValueError(f"data of shape {f.shape} does not match the grid ({xg.size}, {yg.size})")
+    if xg.size > 1 and xg[1] < xg[0]:
+        xg, f = xg[::-1], f[::-1, :]
+    if yg.size > 1 and yg[1] < yg[0]:
+        yg, f = yg[::-1], f[:, ::-1]
+    xg, yg, f = np.ascontiguousarray(xg), np.ascontiguousarray(yg), np.ascontiguousarray(f)
+    out = np.empty_like(px)
+    lib = load()
+    if lib.shk_interp_regular_grid(device, px.size, _ptr(px), _ptr(py), xg.size, yg.size, _ptr(xg), _ptr(yg),
+                                   _ptr(f), 0 if fast_path else 1, _ptr(out)) != 0:
+        raise ShaktiHipError(lib.shk_last_error().decode())
+    return out
+
+
+def points_in_polygon(px, py, poly, device: int = 0) -> np.ndarray:
+    """Even-odd point-in-polygon test on the GPU: True for points inside the (m, 2) polygon (closed or not).
+    Replaces the per-node loop of /root/reference/source/model_setup.py:68-72."""
+    px = np.ascontiguousarray(px, dtype=np.float64).ravel()
+    py = np.ascontiguousarray(py, dtype=np.float64).ravel()
+    poly = np.ascontiguousarray(poly, dtype=np.float64)
+    if poly.ndim != 2 or poly.shape[1] != 2:
+        raise ValueError("polygon must be an (m, 2) array")
+    if poly.shape[0] > 1 and np.array_equal(poly[0], poly[-1]):
+        poly = np.ascontiguousarray(poly[:-1])   # drop the repeated closing vertex (a zero-length edge anyway)
+    out = np.empty_like(px)
+    lib = load()
+    if lib.shk_points_in_polygon(device, px.size, _ptr(px), _ptr(py), poly.shape[0], _ptr(poly), _ptr(out)) != 0:
+        raise ShaktiHipError(lib.shk_last_error().decode())
+    return out != 0.0
 
 
 def _f64(a, shape=None) -> np.ndarray:

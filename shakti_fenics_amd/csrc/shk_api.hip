@@ -18,6 +18,9 @@ static int fail(const std::string& msg) {
     g_err = msg;
     return -1;
 }
+namespace shk {
+int set_error(const std::string& msg) { return fail(msg); }
+}
 
 #define HIPCHK(expr)                                                                              \
     do {                                                                                          \

@@ -403,6 +403,9 @@ __device__ __forceinline__ GroupSweep xcd_sweep(int ngroups, int xcd_local) {
 // partial-array slots; [RR, RHV] and [TS, TT, RHT, RHS] are the two per-iteration reduction groups
 enum { P_RR = 0, P_RHV = 1, P_TS = 2, P_TT = 3, P_RHT = 4, P_RHS = 5, P_AUX = 6, P_COUNT = 8 };
 
+// error text of the calling thread (shk_api.hip: shk_last_error); returns -1
+int set_error(const std::string& msg);
+
 // launchers (shk_kernels.hip)
 hipError_t prepare_kernels(Ctx* c);
 void launch_assemble(Ctx* c, double dt);

@@ -43,6 +43,8 @@ _BUILD_KNOBS = dict(
     setup_file=None,            # optional path copied next to the results (solvers.py:125)
     device=0, krylov_rtol=1e-10, krylov_max_it=20000,
     preconditioner="amg",       # "amg" (default) | "amg_local" | "jacobi" (north_star's solver)
+    ingest="auto",              # where interp_data / set_lake_bdry evaluate: "device" (HIP kernels, bit-identical
+                                # to scipy) | "host" (the reference's own scipy call) | "auto" = device if a GPU is visible
 )
 
 
@@ -73,9 +75,20 @@ class model_setup:
             for j in range(self.lake_bdry.x.array.size):
                 p = Point(self.x[j], self.y[j])
                 self.lake_bdry.x.array[j] = outline.geometry.contains(p).iloc[0]
+        elif self._ingest_on_device():
+            from ._lib import points_in_polygon
+            self.lake_bdry.x.array[:] = points_in_polygon(self.x, self.y, outline, device=self.device)
         else:
             self.lake_bdry.x.array[:] = _points_in_polygon(self.x, self.y, outline)
         self.lake_bdry.x.scatter_forward()
+
+    def _ingest_on_device(self) -> bool:
+        if self.ingest not in ("auto", "device", "host"):
+            raise ValueError(f"md.ingest must be 'auto', 'device' or 'host', not {self.ingest!r}")
+        if self.ingest == "auto":
+            import torch   # device_count() does not initialise the GPU
+            return torch.cuda.device_count() > 0
+        return self.ingest == "device"
 
     def interp_data(self, var_name, x_d, y_d, f):
         """Bilinear interpolation of gridded data f[y, x] to the mesh nodes into `self.<var_name>`
@@ -89,7 +102,12 @@ class model_setup:
         *path, last = f"{var_name}.x.array".split(".")
         for name in path:
             target = getattr(target, name)
-        getattr(target, last)[:] = f_interp(np.column_stack((self.x, self.y)))
+        if self._ingest_on_device():
+            from ._lib import interp_regular_grid   # same numbers as f_interp(points), computed on the GPU
+            getattr(target, last)[:] = interp_regular_grid(self.x, self.y, x_d[mx], y_d[my], f[np.ix_(my, mx)].T,
+                                                           device=self.device)
+        else:
+            getattr(target, last)[:] = f_interp(np.column_stack((self.x, self.y)))
         getattr(self, var_name.split(".")[0]).x.scatter_forward()
         return f_interp
 
