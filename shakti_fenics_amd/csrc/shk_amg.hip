@@ -168,14 +168,14 @@ struct AmgSmoothArgs {
 template <bool FINE, class TX, class TR, class TO>
 __global__ __launch_bounds__(kBlock) void k_amg_post(const AmgSmoothArgs<TX, TR, TO> a) {
     if (*a.done) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const GroupSweep sw = xcd_sweep((a.A.nslice + 3) >> 2, a.A.xcd_local);
-    for (int g = sw.begin; g < sw.end; g += sw.step) {
-        const int s = 4 * g + wave;
-        if (s >= a.A.nslice) break;
-        const auto sum = sell_row_sum(a.A, a.vals, a.x, s, lane);
-        const int row = s * kSlice + lane;
-        if (row < a.A.n_rows) a.xo[row] = (TO)(a.x[row] + a.omega * a.dinv[row] * (a.r[row] - sum));
+    const int lane = threadIdx.x & 63;
+    for (SliceLoop it(a.A, wave_index()); it.valid(); it.next()) {
+        const int row = min(it.s * kSlice + lane, a.A.n_rows - 1);   // tail rows of the last slice: clamped, not stored
+        const TX xr = a.x[row];            // the row's own entries are requested ahead of the slice stream
+        const TR rr = a.r[row];
+        const float di = a.dinv[row];
+        const auto sum = sell_row_sum(a.A, it.m, a.vals, a.x, lane);
+        if (it.s * kSlice + lane < a.A.n_rows) a.xo[row] = (TO)(xr + a.omega * di * (rr - sum));
     }
 }
 
@@ -196,15 +196,14 @@ struct AmgFirstArgs {
 template <bool FINE, class TR>
 __global__ __launch_bounds__(kBlock) void k_amg_first(const AmgFirstArgs<TR> a) {
     if (*a.done) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const GroupSweep sw = xcd_sweep((a.AP.nslice + 3) >> 2, a.AP.xcd_local);
-    for (int g = sw.begin; g < sw.end; g += sw.step) {
-        const int s = 4 * g + wave;
-        if (s >= a.AP.nslice) break;
-        const float sum = sell_row_sum(a.AP, a.vals, a.e, s, lane);
-        const int row = s * kSlice + lane;
-        if (row < a.AP.n_rows)
-            a.xo[row] = a.alpha * a.e[a.agg[row]] + a.omega * a.dinv[row] * ((float)a.r[row] - a.alpha * sum);
+    const int lane = threadIdx.x & 63;
+    for (SliceLoop it(a.AP, wave_index()); it.valid(); it.next()) {
+        const int row = min(it.s * kSlice + lane, a.AP.n_rows - 1);
+        const int ag = a.agg[row];
+        const float rr = (float)a.r[row];
+        const float di = a.dinv[row];
+        const float sum = sell_row_sum(a.AP, it.m, a.vals, a.e, lane);
+        if (it.s * kSlice + lane < a.AP.n_rows) a.xo[row] = a.alpha * a.e[ag] + a.omega * di * (rr - a.alpha * sum);
     }
 }
 
@@ -326,12 +325,9 @@ __global__ __launch_bounds__(kBlock) void k_power_step(const DevSell A, const fl
     __shared__ double sh[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double so = 0.0, sx = 0.0;
-    const GroupSweep sw = xcd_sweep((A.nslice + 3) >> 2, A.xcd_local);
-    for (int g = sw.begin; g < sw.end; g += sw.step) {
-        const int s = 4 * g + wave;
-        if (s >= A.nslice) break;
-        const float sum = sell_row_sum(A, vals, x, s, lane);
-        const int row = s * kSlice + lane;
+    for (SliceLoop it(A, wave_index()); it.valid(); it.next()) {
+        const float sum = sell_row_sum(A, it.m, vals, x, lane);
+        const int row = it.s * kSlice + lane;
         if (row < A.n_rows) {
             const float y = dinv[row] * sum;
             xo[row] = y;

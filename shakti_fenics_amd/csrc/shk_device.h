@@ -116,24 +116,80 @@ __device__ __forceinline__ auto sell_width(const TV* __restrict__ vp, const TC* 
         default: return sum;
     }
 }
+// XCD-aware work distribution for streaming kernels (MI355X: 8 XCDs with private 4 MiB L2s, workgroups are
+// dealt round-robin, so blockIdx % 8 labels the XCD).  Each XCD gets one contiguous eighth of the slice groups
+// and its workgroups sweep it side by side, so the x-vector lines shared by neighbouring rows are fetched into
+// ONE L2 instead of up to eight.  Placement only affects speed, never results.
+struct GroupSweep {
+    int begin, end, step;
+};
+// (Dealing chunks of 4 .. 1024 consecutive groups to the XCDs in turn -- close streams, still XCD-local runs --
+// measured the same as plain round robin at 10M rows: the x vector is served by the Infinity Cache either way.)
+__device__ __forceinline__ GroupSweep xcd_sweep(int ngroups, int xcd_local) {
+    const int nb = gridDim.x, b = blockIdx.x;
+    if (!xcd_local || (nb & 7) != 0) return GroupSweep{b, ngroups, nb};
+    const int per = (ngroups + 7) >> 3, xcd = b & 7;
+    const int g0 = xcd * per;
+    return GroupSweep{g0 + (b >> 3), min(ngroups, g0 + per), nb >> 3};
+}
+
+// Slice descriptor, wave-uniform: kept in SGPRs and fetched through the scalar cache (the slice index must be
+// provably uniform for that: take the wave index through wave_index()).
+struct SellMeta {
+    int base, width, cb, p16;
+};
+__device__ __forceinline__ int wave_index() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+__device__ __forceinline__ SellMeta sell_meta(const DevSell& A, int s) {
+    const int base = A.ptr[s];
+    return SellMeta{base, (A.ptr[s + 1] - base) >> 6, A.cbase[s], A.ptr16[s]};
+}
 template <bool NT, int WMAX, class TV, class TX>
-__device__ __forceinline__ auto sell_row_sum_t(const DevSell& A, const TV* __restrict__ vals,
-                                               const TX* __restrict__ x, int s, int lane) -> decltype(TV() * TX()) {
-    const int base = __builtin_amdgcn_readfirstlane(A.ptr[s]);
-    const int width = (__builtin_amdgcn_readfirstlane(A.ptr[s + 1]) - base) >> 6;
-    const int cb = __builtin_amdgcn_readfirstlane(A.cbase[s]);
-    const TV* __restrict__ vp = vals + base + lane;
-    if (cb >= 0)
-        return sell_width<NT, WMAX>(vp, A.col16 + __builtin_amdgcn_readfirstlane(A.ptr16[s]) + lane, x + cb, width);
-    return sell_width<NT, WMAX>(vp, A.col + base + lane, x, width);
+__device__ __forceinline__ auto sell_row_sum_t(const DevSell& A, const SellMeta& m, const TV* __restrict__ vals,
+                                               const TX* __restrict__ x, int lane) -> decltype(TV() * TX()) {
+    const TV* __restrict__ vp = vals + m.base + lane;
+    if (m.cb >= 0) return sell_width<NT, WMAX>(vp, A.col16 + m.p16 + lane, x + m.cb, m.width);
+    return sell_width<NT, WMAX>(vp, A.col + m.base + lane, x, m.width);
 }
 // WMAX = 8 or 12: widest fully unrolled body (registers against round trips; 12 pays for the double-precision
 // Krylov product, whose slices are up to 11 wide, 8 for the float smoothers)
 template <int WMAX = 8, class TV, class TX>
+__device__ __forceinline__ auto sell_row_sum(const DevSell& A, const SellMeta& m, const TV* __restrict__ vals,
+                                             const TX* __restrict__ x, int lane) -> decltype(TV() * TX()) {
+    return A.xcd_local ? sell_row_sum_t<false, WMAX>(A, m, vals, x, lane) : sell_row_sum_t<true, WMAX>(A, m, vals, x, lane);
+}
+template <int WMAX = 8, class TV, class TX>
 __device__ __forceinline__ auto sell_row_sum(const DevSell& A, const TV* __restrict__ vals,
                                              const TX* __restrict__ x, int s, int lane) -> decltype(TV() * TX()) {
-    return A.xcd_local ? sell_row_sum_t<false, WMAX>(A, vals, x, s, lane) : sell_row_sum_t<true, WMAX>(A, vals, x, s, lane);
+    return sell_row_sum<WMAX>(A, sell_meta(A, s), vals, x, lane);
 }
+
+// The loop every SELL kernel runs: this wave's slices s = 4 g + wave over the workgroup's groups g, with the
+// NEXT slice's descriptor requested (scalar loads) before the current slice's row sum, so that its latency
+// hides behind the value / column stream instead of preceding it.
+//   for (SliceLoop it(A, wave); it.valid(); it.next()) { ... it.s, it.m ... }
+struct SliceLoop {
+    const DevSell& A;
+    GroupSweep sw;
+    int wave, g, s;
+    SellMeta m, mn;
+    __device__ __forceinline__ SliceLoop(const DevSell& A_, int wave_) : A(A_), wave(wave_) {
+        sw = xcd_sweep((A.nslice + 3) >> 2, A.xcd_local);
+        g = sw.begin;
+        s = 4 * g + wave;
+        if (valid()) { m = sell_meta(A, s); prefetch(); }
+    }
+    __device__ __forceinline__ bool valid() const { return g < sw.end && s < A.nslice; }
+    __device__ __forceinline__ void prefetch() {
+        const int sn = 4 * (g + sw.step) + wave;
+        if (g + sw.step < sw.end && sn < A.nslice) mn = sell_meta(A, sn);
+    }
+    __device__ __forceinline__ void next() {
+        g += sw.step;
+        s = 4 * g + wave;
+        m = mn;
+        if (valid()) prefetch();
+    }
+};
 
 // Multigrid down-sweep over four levels in one launch (k_amg_restrict4).  An aligned group of 256 rows holds
 // complete aggregate trees four levels deep (256 = 4^4): one workgroup pass leaves the right-hand sides of
@@ -378,23 +434,6 @@ struct Ctx {
         return A;
     }
 };
-
-// XCD-aware work distribution for streaming kernels (MI355X: 8 XCDs with private 4 MiB L2s, workgroups are
-// dealt round-robin, so blockIdx % 8 labels the XCD).  Each XCD gets one contiguous eighth of the slice groups
-// and its workgroups sweep it side by side, so the x-vector lines shared by neighbouring rows are fetched into
-// ONE L2 instead of up to eight.  Placement only affects speed, never results.
-struct GroupSweep {
-    int begin, end, step;
-};
-// (Dealing chunks of 4 .. 1024 consecutive groups to the XCDs in turn -- close streams, still XCD-local runs --
-// measured the same as plain round robin at 10M rows: the x vector is served by the Infinity Cache either way.)
-__device__ __forceinline__ GroupSweep xcd_sweep(int ngroups, int xcd_local) {
-    const int nb = gridDim.x, b = blockIdx.x;
-    if (!xcd_local || (nb & 7) != 0) return GroupSweep{b, ngroups, nb};
-    const int per = (ngroups + 7) >> 3, xcd = b & 7;
-    const int g0 = xcd * per;
-    return GroupSweep{g0 + (b >> 3), min(ngroups, g0 + per), nb >> 3};
-}
 
 // Matrix stream loads: a matrix that cannot stay in the Infinity Cache is read non-temporally so that it does
 // not evict the x vector (measured at 10M rows: -3 % time); a cache-resident one is read normally (non-temporal

@@ -328,18 +328,18 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const SpmvArgs a) {
     if (MODE != 0) {
         if (a.st->done) return;
     }
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
     double d0 = 0.0, d1 = 0.0, d2 = 0.0;
-    const GroupSweep sw = xcd_sweep((a.A.nslice + 3) >> 2, a.A.xcd_local);
-    for (int g = sw.begin; g < sw.end; g += sw.step) {
-        const int s = 4 * g + wave;
-        if (s >= a.A.nslice) break;
-        const double sum = sell_row_sum<12>(a.A, a.vals, a.x, s, lane);
-        const int row = s * kSlice + lane;
-        if (row < a.A.n_rows) {
+    for (SliceLoop it(a.A, wave_index()); it.valid(); it.next()) {
+        const int row = min(it.s * kSlice + lane, a.A.n_rows - 1);   // tail rows of the last slice: clamped, not used
+        // the dot-product operands are requested ahead of the slice stream
+        const double rh = MODE != 0 ? a.rhat[row] : 0.0;
+        const double sd = MODE == 2 ? a.sdot[row] : 0.0;
+        const double sum = sell_row_sum<12>(a.A, it.m, a.vals, a.x, lane);
+        if (it.s * kSlice + lane < a.A.n_rows) {
             a.y[row] = sum;
-            if (MODE == 1) d0 += a.rhat[row] * sum;
-            if (MODE == 2) { d0 += sum * a.sdot[row]; d1 += sum * sum; d2 += a.rhat[row] * sum; }
+            if (MODE == 1) d0 += rh * sum;
+            if (MODE == 2) { d0 += sum * sd; d1 += sum * sum; d2 += rh * sum; }
         }
     }
     if (MODE == 1) {
