@@ -29,7 +29,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s is the mea
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=8,
+                    help="timed steps; 8 = one rebuild period of the multigrid's dense coarsest inverse, so the default "
+                         "run pays for exactly one rebuild inside the timed region")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="c4_10m", help="c1_5k | c1_12k | c2_1m | c4_10m (default: the 10M-DOF mesh)")
     ap.add_argument("--order", default="morton")

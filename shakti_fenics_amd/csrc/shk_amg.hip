@@ -631,10 +631,15 @@ hipError_t amg_vcycle(Ctx* c, const double* rin, double* zout) {
             launch_post<true>(c, A, c->d_vals32, c->d_dinv32, rin, (const float*)H.x0, zout, w2, done);
         } else {
             const AmgLevel& L = H.lv[l];
+            // coarse levels are cheap next to the finest one, and a better coarse solve pays: four sweeps with the
+            // Chebyshev dampings H.c4 instead of two (levels that would need a ghost exchange per sweep keep two)
+            const bool more = H.coarse4 && !halo;
+            const float lw1 = more ? (float)(H.c4[0] / H.lambda) : w1;
+            const float lw2 = more ? (float)(H.c4[1] / H.lambda) : w2;
             if (fused) {
                 AmgFirstArgs<float> f{DevSell{X.n_fine, X.n_coarse_cols, X.ap_nslice, sell_fits_cache(X.ap_slots, kAmgSlotBytes),
                                               X.ap_ptr, X.ap_col, X.ap_rowlen, X.ap_cbase, X.ap_ptr16, X.ap_col16},
-                                      X.ap_vals, L.dinv, L.r, ec, X.agg, L.x, omega, alpha, done};
+                                      X.ap_vals, L.dinv, L.r, ec, X.agg, L.x, lw1, alpha, done};
                 PhaseTimer t(c, SHK_PH_AMG_COARSE);
                 hipLaunchKernelGGL((k_amg_first<false, float>), g, dim3(kBlock), 0, c->stream, f);
             } else {
@@ -647,11 +652,15 @@ hipError_t amg_vcycle(Ctx* c, const double* rin, double* zout) {
                 // (without the exchange the ghost entries stay zero = block-local smoothing on that level)
                 if (halo && (e = halo_exchange_plan_f32(c, *HP, L.x2)) != hipSuccess) return e;
                 PhaseTimer t(c, SHK_PH_AMG_COARSE);
-                launch_post<false>(c, A, L.vals, L.dinv, (const float*)L.r, (const float*)L.x2, L.x, w1, done);
+                launch_post<false>(c, A, L.vals, L.dinv, (const float*)L.r, (const float*)L.x2, L.x, lw1, done);
             }
             if (halo && (e = halo_exchange_plan_f32(c, *HP, L.x)) != hipSuccess) return e;
             PhaseTimer t(c, SHK_PH_AMG_COARSE);
-            launch_post<false>(c, A, L.vals, L.dinv, (const float*)L.r, (const float*)L.x, L.x2, w2, done);
+            launch_post<false>(c, A, L.vals, L.dinv, (const float*)L.r, (const float*)L.x, L.x2, lw2, done);
+            if (more) {
+                launch_post<false>(c, A, L.vals, L.dinv, (const float*)L.r, (const float*)L.x2, L.x, (float)(H.c4[2] / H.lambda), done);
+                launch_post<false>(c, A, L.vals, L.dinv, (const float*)L.r, (const float*)L.x, L.x2, (float)(H.c4[3] / H.lambda), done);
+            }
         }
     }
     return hipSuccess;

@@ -191,6 +191,7 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
         LP = AmgLevelPlan();  // host copy no longer needed
     }
     if (const char* sa = getenv("SHK_AMG_ALPHA")) H.alpha = atof(sa);
+    if (const char* sa = getenv("SHK_AMG_COARSE4")) H.coarse4 = atoi(sa) != 0;
     if (const char* sa = getenv("SHK_AMG_DENSE_PERIOD")) H.dense_period = std::max(1, atoi(sa));
     if ((e = dev_alloc(c, &H.x0, (size_t)n_loc0)) != hipSuccess) return e;
     if ((e = dev_alloc(c, &H.x1, (size_t)n_loc0)) != hipSuccess) return e;

@@ -333,6 +333,12 @@ struct AmgHierarchy {
     // 0.6; 61 iterations per Newton step against 69 for 0.7, 0.7 -- and 0.9, 0.9 diverges).  (SHK_AMG_W1/W2)
     double lambda = 0.0;             // 0: not estimated yet
     double c1 = 2.35, c2 = 1.41;
+    // Levels >= 1 without ghost exchanges run FOUR sweeps, dampings c4[k] / lambda = the Chebyshev roots for
+    // [0.25, 0.9] lambda, small and large steps interleaved.  Measured ms/step at 10M | 1M rows: two sweeps
+    // 253 | 43.0; four with (c1, c2) twice 238 | 43.3; Chebyshev on [0.37, 0.77] 242 | 44, [0.25, 0.8] 230 | 39.4,
+    // [0.2, 0.8] 223 | 41.5, [0.25, 0.9] 225 | 41.7; [0.15, 0.8] and [0.25, 0.7] diverge at 10M rows (SHK_AMG_COARSE4=0)
+    bool coarse4 = true;
+    double c4[4] = {1.143, 3.640, 1.430, 2.219};
     int64_t ap_nnz0 = 0;             // stored entries of the finest level's A*P operator
     int32_t n_glob = 0, offset = 0;  // dense coarsest operator: n_glob x n_glob, my rows start at `offset`
     float *x0 = nullptr, *x1 = nullptr, *cr = nullptr, *cx = nullptr;   // x1: power-iteration scratch (finest level)

@@ -754,8 +754,10 @@ PhaseTimer::PhaseTimer(Ctx* c_, int phase) : c(c_) {
     if (!c->profiling) return;
     if (c->ev_used == c->ev_pool.size()) {
         Ctx::Ev e;
-        (void)hipEventCreate(&e.a);
-        (void)hipEventCreate(&e.b);
+        // no system-scope fence at the events: a default event flushes / invalidates the caches around every
+        // timed launch, which showed as ~15 us per launch against the rocprofv3 trace of the same kernels
+        (void)hipEventCreateWithFlags(&e.a, hipEventDisableSystemFence);
+        (void)hipEventCreateWithFlags(&e.b, hipEventDisableSystemFence);
         c->ev_pool.push_back(e);
     }
     idx = (int)c->ev_used++;

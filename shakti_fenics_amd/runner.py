@@ -23,8 +23,9 @@ def _pmc_traffic(config, nv):
         return {}
     k = json.load(open(path))["kernels"]
     out = {"source": f"profiles/pmc_traffic_{config}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
-    if "amg_fine" in k:
-        out["amg_fine"] = k["amg_fine"]["hbm_bytes"]
+    for key in ("amg_fine", "amg_first"):
+        if key in k:
+            out[key] = k[key]["hbm_bytes"]
     if "spmv1" in k and "spmv2" in k:
         out["spmv"] = 0.5 * (k["spmv1"]["hbm_bytes"] + k["spmv2"]["hbm_bytes"])
     if "assemble" in k:
