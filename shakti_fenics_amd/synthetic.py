@@ -36,7 +36,7 @@ def surface(x, y):
 
 
 def synthetic_fields(dom: Domain, storage_on: bool = True, moulins: int = 0, seed_b: int = 0,
-                     seed_moulin: int = 7, moulin_Q: float = 5.0) -> dict:
+                     seed_moulin: int = 7, moulin_Q: float = 5.0, moulin_radius: float = 150.0) -> dict:
     """Dict of per-vertex float64 arrays: z_b, z_s, G, inputs, b_init, N_init, q_init (nv,2),
     lake_bdry.  b_init = 0.001 + N(0, 0.005) (setup_cooke2.py:66, seeded here),
     N_init = N_bdry (:67), q_init = 0 (:68-69), inputs = 0 or `moulins` point sources (:89)."""
@@ -49,12 +49,23 @@ def synthetic_fields(dom: Domain, storage_on: bool = True, moulins: int = 0, see
     lake = ((x - 0.5 * Lx) ** 2 + (y - 0.5 * Ly) ** 2 < 5e3 ** 2).astype(np.float64)
     inputs = np.zeros(nv)
     if moulins > 0:
-        # Q_m spread over the lumped (1/3 of the incident cell areas) area of the chosen vertex
+        # Each moulin delivers Q_m over a footprint of radius `moulin_radius` around a chosen vertex (weights
+        # 1 - (d/R)^2, normalised with the lumped vertex areas so that the discharge is exactly Q_m).  A footprint
+        # fixed in metres keeps the forcing the same under mesh refinement: a true point source makes the head
+        # at the source node grow like log(1/h), and at h = 14 m (10M vertices) Newton no longer converges
+        # after a few steps.  Meshes coarser than the radius degenerate to the single-vertex source.
         pick_grid = np.random.default_rng(seed_moulin).choice(nv, size=moulins, replace=False)
         sel = np.zeros(nv)
         sel[pick_grid] = 1.0
-        sel = _grid_to_vertex(dom, sel) > 0.5
-        inputs[sel] = moulin_Q / lumped_area(dom)[sel]
+        centres = np.nonzero(_grid_to_vertex(dom, sel) > 0.5)[0]
+        area = lumped_area(dom)
+        R = float(moulin_radius)
+        for v in centres:
+            near = np.nonzero((np.abs(x - x[v]) < R) & (np.abs(y - y[v]) < R))[0]
+            w = np.maximum(0.0, 1.0 - ((x[near] - x[v]) ** 2 + (y[near] - y[v]) ** 2) / (R * R)) if R > 0 else np.zeros(near.size)
+            if not np.any(w > 0):
+                near, w = np.array([v]), np.array([1.0])
+            inputs[near] += moulin_Q * w / np.sum(w * area[near])
     return dict(
         z_b=bed(x, y), z_s=surface(x, y), G=np.full(nv, 0.05), inputs=inputs,
         b_init=b_init, N_init=np.full(nv, N_BDRY), q_init=np.zeros((nv, 2)),
