@@ -373,8 +373,11 @@ static hipError_t estimate_lambda(Ctx* c, AmgHierarchy& H) {
         const int grid = std::min((A.nslice + 3) / 4, 2048);
         hipLaunchKernelGGL(k_power_init, dim3(std::min(1024, (A.n_cols + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
                            A.n_rows, A.n_cols, xa);
-        hipError_t e = hipMemsetAsync(xb, 0, (size_t)A.n_cols * sizeof(float), c->stream);
-        if (e != hipSuccess) return e;
+        // the second buffer's ghost columns must read as zero (the kernels only write owned rows)
+        hipError_t e = hipSuccess;
+        if (A.n_cols > A.n_rows &&
+            (e = hipMemsetAsync(xb + A.n_rows, 0, (size_t)(A.n_cols - A.n_rows) * sizeof(float), c->stream)) != hipSuccess)
+            return e;
         for (int k = 0; k < steps; ++k) {
             if (k + 1 < steps)
                 hipLaunchKernelGGL(k_power_step<false>, dim3(grid), dim3(kBlock), 0, c->stream, A, vals, dinv,
@@ -390,9 +393,7 @@ static hipError_t estimate_lambda(Ctx* c, AmgHierarchy& H) {
         double so = 0.0, sx = 0.0;
         for (int b = 0; b < grid; ++b) { so += h[b]; sx += h[kMaxParts + b]; }
         if (sx > 0.0 && std::isfinite(so)) lam = std::max(lam, std::sqrt(so / sx));
-        // the scratch vectors go back to zero: their ghost columns must read as zero in block-local sweeps
-        if ((e = hipMemsetAsync(xa, 0, (size_t)A.n_cols * sizeof(float), c->stream)) != hipSuccess) return e;
-        if ((e = hipMemsetAsync(xb, 0, (size_t)A.n_cols * sizeof(float), c->stream)) != hipSuccess) return e;
+        // (the scratch vectors' ghost columns are still zero, and every V-cycle overwrites their owned rows first)
     }
     // subdomains must agree on the damping: take the largest estimate
     if (c->comm.kind != Comm::NONE && c->comm.nranks > 1) {
