@@ -49,9 +49,18 @@ def make_context(sub: Subdomain, device: int, transport: str = "rccl", group=Non
     if sub.nranks == 1:
         return ctx
     if transport == "rccl":
-        obj = [_lib.rccl_unique_id() if sub.rank == 0 else None]
-        dist.broadcast_object_list(obj, src=0, group=group)
-        ctx.comm_init_rccl(sub.rank, sub.nranks, obj[0])
+        # every rank must take the same branch: agree on success before anyone enters the data path
+        err = ""
+        try:
+            obj = [_lib.rccl_unique_id() if sub.rank == 0 else None]
+            dist.broadcast_object_list(obj, src=0, group=group)
+            ctx.comm_init_rccl(sub.rank, sub.nranks, obj[0])
+        except Exception as exc:   # noqa: BLE001 -- reported below, on every rank
+            err = f"rank {sub.rank}: {exc}"
+        errs = [None] * sub.nranks
+        dist.all_gather_object(errs, err, group=group)
+        if any(errs):
+            raise _lib.ShaktiHipError("RCCL communicator could not be created: " + "; ".join(e for e in errs if e))
     elif transport == "gloo":
         ex, ar = gloo_callbacks(group)
         ctx.comm_init_callbacks(sub.rank, sub.nranks, ex, ar)

@@ -169,6 +169,7 @@ class PartitionedRunner(SingleRunner):
             t = t.cuda(device)
         dist.all_reduce(t, group=group)
         self.nnz_global = int(t.item())
+        self.transport = transport
         self._desc = (f"{Lx/1e3:.0f} km x {Ly/1e3:.0f} km rectangle, {nx}x{ny} jittered P1 mesh ({order} order), "
                       f"dt {dt:g} s (first step 0.1 dt), storage {'on' if storage else 'off'}, {moulins} moulins, "
                       f"Dirichlet N = {N_BDRY:g} Pa on x = 0; {world} subdomains (RCB), {transport} halo")
@@ -192,6 +193,20 @@ def make_runner(args, rank: int, world: int, local_rank: int):
     if world == 1:
         return SingleRunner(args.config, args.order, args.dt, bool(args.storage), args.moulins, local_rank,
                             args.krylov_rtol, precond=getattr(args, "precond", "amg"))
-    return PartitionedRunner(rank, world, local_rank, args.config, args.order, args.dt, bool(args.storage),
-                             args.moulins, args.krylov_rtol, transport=getattr(args, "transport", "rccl"),
-                             precond=getattr(args, "precond", "amg"))
+    transport = getattr(args, "transport", "rccl")
+    kw = dict(precond=getattr(args, "precond", "amg"))
+    try:
+        return PartitionedRunner(rank, world, local_rank, args.config, args.order, args.dt, bool(args.storage),
+                                 args.moulins, args.krylov_rtol, transport=transport, **kw)
+    except _lib.ShaktiHipError as exc:
+        if transport != "rccl" or "RCCL communicator" not in str(exc):
+            raise
+        # The data path cannot use RCCL on this node (the error is collective: every rank is here).  Run the same
+        # solver over the host-staged transport instead of producing nothing, and say so in the workload string.
+        import sys
+        import torch.distributed as dist
+        print(f"[bench] WARNING rank {rank}: {exc}; continuing with the host-staged gloo transport", file=sys.stderr,
+              flush=True)
+        group = dist.new_group(backend="gloo")
+        return PartitionedRunner(rank, world, local_rank, args.config, args.order, args.dt, bool(args.storage),
+                                 args.moulins, args.krylov_rtol, transport="gloo", group=group, **kw)
