@@ -529,7 +529,7 @@ static void launch_post(Ctx* c, const DevSell& A, const float* vals, const float
 }
 
 // z = M^-1 r : one V(0,2) cycle.  r and z have the fine level's length; r is not modified.
-hipError_t amg_vcycle(Ctx* c, const double* rin, double* zout) {
+hipError_t amg_vcycle(Ctx* c, const double* rin, float* zout) {
     AmgHierarchy& H = *c->amg;
     const size_t nx = H.xf.size();  // levels 0..nx-1 are sparse, level nx is the dense coarsest
     const int* done = &c->d_state->done;
@@ -542,7 +542,7 @@ hipError_t amg_vcycle(Ctx* c, const double* rin, double* zout) {
     if (c->n_loc > c->n_own && !(H.distributed && H.halo_levels > 0)) {
         // block-local smoothing on the finest level: the output vector's ghost entries (left over from the Krylov
         // loop's own exchange) must read as zero, or the preconditioner would change from call to call
-        if ((e = hipMemsetAsync(zout + c->n_own, 0, (size_t)(c->n_loc - c->n_own) * sizeof(double), c->stream)) != hipSuccess)
+        if ((e = hipMemsetAsync(zout + c->n_own, 0, (size_t)(c->n_loc - c->n_own) * sizeof(float), c->stream)) != hipSuccess)
             return e;
     }
     {
@@ -609,8 +609,7 @@ hipError_t amg_vcycle(Ctx* c, const double* rin, double* zout) {
         const DevSell A = level_sell(c, H, l);
         const dim3 g(std::min((A.nslice + 3) / 4, 2048));
         if (l == 0) {
-            // level 0: right-hand side = the Krylov vector, result = the preconditioned Krylov vector (both double),
-            // the iterate in between lives in the float scratch x0
+            // level 0: right-hand side = the Krylov vector (double); the iterate and the result are float
             if (fused) {
                 AmgFirstArgs<double> f{DevSell{X.n_fine, X.n_coarse_cols, X.ap_nslice, sell_fits_cache(X.ap_slots, kAmgSlotBytes),
                                                X.ap_ptr, X.ap_col, X.ap_rowlen, X.ap_cbase, X.ap_ptr16, X.ap_col16},
@@ -620,12 +619,12 @@ hipError_t amg_vcycle(Ctx* c, const double* rin, double* zout) {
             } else {
                 {
                     PhaseTimer t(c, SHK_PH_AMG_COARSE);
-                    hipLaunchKernelGGL(k_amg_prolong<double>, dim3(small_grid(X.n_fine)), dim3(kBlock), 0, c->stream,
+                    hipLaunchKernelGGL(k_amg_prolong<float>, dim3(small_grid(X.n_fine)), dim3(kBlock), 0, c->stream,
                                        X.n_fine, alpha, X.agg, ec, zout, done);
                 }
-                if (halo && (e = halo_exchange_plan(c, *HP, zout)) != hipSuccess) return e;
+                if (halo && (e = halo_exchange_plan_f32(c, *HP, zout)) != hipSuccess) return e;
                 PhaseTimer t(c, SHK_PH_AMG_FINE);
-                launch_post<true>(c, A, c->d_vals32, c->d_dinv32, rin, (const double*)zout, H.x0, w1, done);
+                launch_post<true>(c, A, c->d_vals32, c->d_dinv32, rin, (const float*)zout, H.x0, w1, done);
             }
             if (halo && (e = halo_exchange_plan_f32(c, *HP, H.x0)) != hipSuccess) return e;
             PhaseTimer t(c, SHK_PH_AMG_FINE);

@@ -328,10 +328,10 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
         c->plan.amg = std::vector<AmgLevelPlan>();
     }
     {
-        double** vs[] = {&c->d_phat, &c->d_shat};
-        for (double** v : vs) {
+        float** vs[] = {&c->d_phat, &c->d_shat};
+        for (float** v : vs) {
             if ((e = dev_alloc(c, v, nl)) != hipSuccess) return bail(e, "amg alloc");
-            if ((e = hipMemset(*v, 0, nl * sizeof(double))) != hipSuccess) return bail(e, "memset");
+            if ((e = hipMemset(*v, 0, nl * sizeof(float))) != hipSuccess) return bail(e, "memset");
         }
     }
     *out = reinterpret_cast<shk_ctx*>(c);

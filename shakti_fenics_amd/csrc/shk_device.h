@@ -413,7 +413,7 @@ struct Ctx {
     // multigrid preconditioner (empty when unavailable: subdomain contexts, tiny meshes)
     AmgHierarchy amg_local, amg_dist;
     AmgHierarchy* amg = nullptr;    // the active one when use_amg
-    double *d_phat = nullptr, *d_shat = nullptr;
+    float *d_phat = nullptr, *d_shat = nullptr;   // M^-1 p, M^-1 s: float, like everything the cycle produces
     bool use_amg = false;
     double* d_part = nullptr;  // 8 arrays of kMaxParts: this subdomain's partial sums
     double* d_red = nullptr;   // the same summed over subdomains (== d_part for a single context)
@@ -481,7 +481,7 @@ hipError_t halo_exchange_plan_f32(Ctx* c, const HaloPlan& P, float* vec);
 hipError_t allreduce_buffer(Ctx* c, const double* src, double* dst, size_t n);  // element-wise sum over subdomains
 int amg_setup_distributed(Ctx* c, std::string& err);  // collective
 hipError_t amg_numeric_setup(Ctx* c, bool refresh_dense);
-hipError_t amg_vcycle(Ctx* c, const double* rin, double* zout);
+hipError_t amg_vcycle(Ctx* c, const double* rin, float* zout);
 // upload one host hierarchy (shk_api.hip: owns the allocation helpers)
 hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H, int64_t n_loc0);
 hipError_t allreduce_parts(Ctx* c, int first, int nslots);

@@ -313,7 +313,7 @@ void launch_scale(Ctx* c) {
 struct SpmvArgs {
     DevSell A;
     const double* vals;
-    const double* x;
+    const void* x;           // double (Jacobi: p, s themselves) or float (the multigrid cycle's M^-1 p, M^-1 s): template TX
     double* y;
     const double* rhat;
     const double* sdot;      // MODE 2: the vector s of (t . s) (== x unless a preconditioner sits in between)
@@ -321,7 +321,7 @@ struct SpmvArgs {
     KrylovState* st;
 };
 
-template <int MODE>
+template <int MODE, class TX>
 __global__ __launch_bounds__(kBlock) void k_spmv(const SpmvArgs a) {
     __shared__ double sh4[4];
     const int tid = threadIdx.x;
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const SpmvArgs a) {
         // the dot-product operands are requested ahead of the slice stream
         const double rh = MODE != 0 ? a.rhat[row] : 0.0;
         const double sd = MODE == 2 ? a.sdot[row] : 0.0;
-        const double sum = sell_row_sum<12>(a.A, it.m, a.vals, a.x, lane);
+        const double sum = sell_row_sum<12>(a.A, it.m, a.vals, reinterpret_cast<const TX*>(a.x), lane);
         if (it.s * kSlice + lane < a.A.n_rows) {
             a.y[row] = sum;
             if (MODE == 1) d0 += rh * sum;
@@ -358,16 +358,16 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const SpmvArgs a) {
     }
 }
 
-static SpmvArgs spmv_args(Ctx* c, const double* vals, const double* x, double* y) {
+static SpmvArgs spmv_args(Ctx* c, const double* vals, const void* x, double* y) {
     SpmvArgs a;
     a.A = c->sell();
-    a.vals = vals; a.x = x; a.y = y; a.rhat = c->d_rhat; a.sdot = x; a.part = c->d_part; a.st = c->d_state;
+    a.vals = vals; a.x = x; a.y = y; a.rhat = c->d_rhat; a.sdot = nullptr; a.part = c->d_part; a.st = c->d_state;
     return a;
 }
 
 void launch_spmv_plain(Ctx* c, const double* vals, const double* x, double* y) {
     PhaseTimer t(c, SHK_PH_SPMV);
-    hipLaunchKernelGGL(k_spmv<0>, dim3(c->grid), dim3(kBlock), 0, c->stream, spmv_args(c, vals, x, y));
+    hipLaunchKernelGGL((k_spmv<0, double>), dim3(c->grid), dim3(kBlock), 0, c->stream, spmv_args(c, vals, x, y));
 }
 
 // ------------------------------------------------------------------ vector kernels
@@ -462,10 +462,11 @@ __global__ __launch_bounds__(kBlock) void k_bicg_s(int64_t n, int it, int max_it
 }
 
 // Closes iteration `it` (it >= 0) and prepares p for iteration it+1.
+template <class TP>   // double: phat, shat alias p, s (Jacobi); float: the multigrid cycle's outputs
 __global__ __launch_bounds__(kBlock) void k_bicg_u(int64_t n, int it, int np, const double* red, double* part,
                                                    const double* __restrict__ s, const double* __restrict__ t,
-                                                   const double* __restrict__ v, double* p, const double* phat,
-                                                   const double* shat, double* __restrict__ y,
+                                                   const double* __restrict__ v, double* p, const TP* phat,
+                                                   const TP* shat, double* __restrict__ y,
                                                    double* __restrict__ r, KrylovState* __restrict__ st) {
     __shared__ double sh4[4];
     if (st->done) return;
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(kBlock) void k_bicg_u(int64_t n, int it, int np, co
     double a = 0.0;
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         const double si = s[i], pi = p[i];
-        y[i] += alpha * phat[i] + omega * shat[i];  // phat = M^-1 p, shat = M^-1 s (aliases of p, s for Jacobi)
+        y[i] += alpha * (double)phat[i] + omega * (double)shat[i];  // phat = M^-1 p, shat = M^-1 s (aliases of p, s for Jacobi)
         const double ri = si - omega * t[i];
         r[i] = ri;
         p[i] = ri + beta * (pi - omega * v[i]);
@@ -550,15 +551,18 @@ hipError_t krylov_iteration(Ctx* c, int it) {
     const dim3 g(c->grid), b(kBlock);
     double* part = c->d_part;
     hipError_t e;
-    // right preconditioner: Jacobi is folded into the matrix (A' = A D^-1, phat = p); multigrid is applied
+    // right preconditioner: Jacobi is folded into the matrix (A' = A D^-1, phat = p); multigrid is applied and
+    // leaves M^-1 p, M^-1 s in float (the product and the solution update read them as such)
     const double* A = c->use_amg ? c->d_vals : c->d_vals_s;
-    double* phat = c->use_amg ? c->d_phat : c->d_p;
-    double* shat = c->use_amg ? c->d_shat : c->d_s;
-    if (c->use_amg && (e = amg_vcycle(c, c->d_p, phat)) != hipSuccess) return e;
-    if ((e = halo_exchange(c, phat)) != hipSuccess) return e;
+    const bool amg = c->use_amg;
+    if (amg) {
+        if ((e = amg_vcycle(c, c->d_p, c->d_phat)) != hipSuccess) return e;
+        if (!c->comm.plans.empty() && (e = halo_exchange_plan_f32(c, c->comm.plans[0], c->d_phat)) != hipSuccess) return e;
+    } else if ((e = halo_exchange(c, c->d_p)) != hipSuccess) return e;
     {
         PhaseTimer t(c, SHK_PH_SPMV);
-        hipLaunchKernelGGL(k_spmv<1>, g, b, 0, c->stream, spmv_args(c, A, phat, c->d_v));
+        if (amg) hipLaunchKernelGGL((k_spmv<1, float>), g, b, 0, c->stream, spmv_args(c, A, c->d_phat, c->d_v));
+        else hipLaunchKernelGGL((k_spmv<1, double>), g, b, 0, c->stream, spmv_args(c, A, c->d_p, c->d_v));
     }
     if ((e = allreduce_parts(c, P_RR, 2)) != hipSuccess) return e;
     {
@@ -566,19 +570,26 @@ hipError_t krylov_iteration(Ctx* c, int it) {
         hipLaunchKernelGGL(k_bicg_s, g, b, 0, c->stream, c->n_own, it, c->params.krylov_max_it, c->cur_rtol2,
                            c->cur_atol2, c->np, c->d_red, part, c->d_r, c->d_v, c->d_rhat, c->d_s, c->d_state);
     }
-    if (c->use_amg && (e = amg_vcycle(c, c->d_s, shat)) != hipSuccess) return e;
-    if ((e = halo_exchange(c, shat)) != hipSuccess) return e;
+    if (amg) {
+        if ((e = amg_vcycle(c, c->d_s, c->d_shat)) != hipSuccess) return e;
+        if (!c->comm.plans.empty() && (e = halo_exchange_plan_f32(c, c->comm.plans[0], c->d_shat)) != hipSuccess) return e;
+    } else if ((e = halo_exchange(c, c->d_s)) != hipSuccess) return e;
     {
         PhaseTimer t(c, SHK_PH_SPMV);
-        SpmvArgs a = spmv_args(c, A, shat, c->d_t);
+        SpmvArgs a = spmv_args(c, A, amg ? (const void*)c->d_shat : (const void*)c->d_s, c->d_t);
         a.sdot = c->d_s;
-        hipLaunchKernelGGL(k_spmv<2>, g, b, 0, c->stream, a);
+        if (amg) hipLaunchKernelGGL((k_spmv<2, float>), g, b, 0, c->stream, a);
+        else hipLaunchKernelGGL((k_spmv<2, double>), g, b, 0, c->stream, a);
     }
     if ((e = allreduce_parts(c, P_TS, 4)) != hipSuccess) return e;
     {
         PhaseTimer t(c, SHK_PH_VECTOR);
-        hipLaunchKernelGGL(k_bicg_u, g, b, 0, c->stream, c->n_own, it, c->np, c->d_red, part, c->d_s, c->d_t, c->d_v,
-                           c->d_p, phat, shat, c->d_y, c->d_r, c->d_state);
+        if (amg)
+            hipLaunchKernelGGL(k_bicg_u<float>, g, b, 0, c->stream, c->n_own, it, c->np, c->d_red, part, c->d_s, c->d_t, c->d_v,
+                               c->d_p, (const float*)c->d_phat, (const float*)c->d_shat, c->d_y, c->d_r, c->d_state);
+        else
+            hipLaunchKernelGGL(k_bicg_u<double>, g, b, 0, c->stream, c->n_own, it, c->np, c->d_red, part, c->d_s, c->d_t, c->d_v,
+                               c->d_p, (const double*)c->d_p, (const double*)c->d_s, c->d_y, c->d_r, c->d_state);
     }
     return hipSuccess;
 }
