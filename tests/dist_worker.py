@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--out", default="")
     ap.add_argument("--precond", default="jacobi")
+    ap.add_argument("--lx", type=float, default=20e3)
+    ap.add_argument("--ly", type=float, default=10e3)
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -38,7 +40,7 @@ def main():
         dist.init_process_group("gloo")
     from shakti_fenics_amd.runner import PartitionedRunner, SingleRunner
 
-    shape = (a.nx, a.ny, 20e3, 10e3)
+    shape = (a.nx, a.ny, a.lx, a.ly)
     run = PartitionedRunner(rank, world, dev, shape=shape, storage=True, transport=a.transport, precond=a.precond)
     infos = []
     for i in range(a.steps):
