@@ -525,7 +525,8 @@ static void launch_post(Ctx* c, const DevSell& A, const float* vals, const float
                         float w, const int* done) {
     AmgSmoothArgs<TX, TR, TO> a{A, vals, dinv, r, x, xo, w, done};
     const dim3 g(std::min((A.nslice + 3) / 4, 2048));
-    hipLaunchKernelGGL((k_amg_post<FINE, TX, TR, TO>), g, dim3(kBlock), 0, c->stream, a);
+    if (FINE) launch_phase(c, SHK_PH_AMG_FINE, k_amg_post<FINE, TX, TR, TO>, g, dim3(kBlock), 0, a);
+    else hipLaunchKernelGGL((k_amg_post<FINE, TX, TR, TO>), g, dim3(kBlock), 0, c->stream, a);
 }
 
 // z = M^-1 r : one V(0,2) cycle.  r and z have the fine level's length; r is not modified.
@@ -614,8 +615,7 @@ hipError_t amg_vcycle(Ctx* c, const double* rin, float* zout) {
                 AmgFirstArgs<double> f{DevSell{X.n_fine, X.n_coarse_cols, X.ap_nslice, sell_fits_cache(X.ap_slots, kAmgSlotBytes),
                                                X.ap_ptr, X.ap_col, X.ap_rowlen, X.ap_cbase, X.ap_ptr16, X.ap_col16},
                                        X.ap_vals, c->d_dinv32, rin, ec, X.agg, H.x0, omega, alpha, done};
-                PhaseTimer t(c, SHK_PH_AMG_FIRST);
-                hipLaunchKernelGGL((k_amg_first<true, double>), g, dim3(kBlock), 0, c->stream, f);
+                launch_phase(c, SHK_PH_AMG_FIRST, k_amg_first<true, double>, g, dim3(kBlock), 0, f);
             } else {
                 {
                     PhaseTimer t(c, SHK_PH_AMG_COARSE);
@@ -623,11 +623,9 @@ hipError_t amg_vcycle(Ctx* c, const double* rin, float* zout) {
                                        X.n_fine, alpha, X.agg, ec, zout, done);
                 }
                 if (halo && (e = halo_exchange_plan_f32(c, *HP, zout)) != hipSuccess) return e;
-                PhaseTimer t(c, SHK_PH_AMG_FINE);
                 launch_post<true>(c, A, c->d_vals32, c->d_dinv32, rin, (const float*)zout, H.x0, w1, done);
             }
             if (halo && (e = halo_exchange_plan_f32(c, *HP, H.x0)) != hipSuccess) return e;
-            PhaseTimer t(c, SHK_PH_AMG_FINE);
             launch_post<true>(c, A, c->d_vals32, c->d_dinv32, rin, (const float*)H.x0, zout, w2, done);
         } else {
             const AmgLevel& L = H.lv[l];

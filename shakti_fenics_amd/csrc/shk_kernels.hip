@@ -278,8 +278,7 @@ static void fill_asm_args(Ctx* c, double dt, AsmArgs& a) {
 void launch_assemble(Ctx* c, double dt) {
     AsmArgs a;
     fill_asm_args(c, dt, a);
-    PhaseTimer t(c, SHK_PH_ASSEMBLE);
-    hipLaunchKernelGGL(k_assemble, dim3(c->nblk), dim3(kBlock), c->asm_lds, c->stream, a);
+    launch_phase(c, SHK_PH_ASSEMBLE, k_assemble, dim3(c->nblk), dim3(kBlock), c->asm_lds, a);
 }
 
 // Dynamic LDS above 64 KiB has to be requested per kernel.
@@ -366,8 +365,7 @@ static SpmvArgs spmv_args(Ctx* c, const double* vals, const void* x, double* y) 
 }
 
 void launch_spmv_plain(Ctx* c, const double* vals, const double* x, double* y) {
-    PhaseTimer t(c, SHK_PH_SPMV);
-    hipLaunchKernelGGL((k_spmv<0, double>), dim3(c->grid), dim3(kBlock), 0, c->stream, spmv_args(c, vals, x, y));
+    launch_phase(c, SHK_PH_SPMV, k_spmv<0, double>, dim3(c->grid), dim3(kBlock), 0, spmv_args(c, vals, x, y));
 }
 
 // ------------------------------------------------------------------ vector kernels
@@ -559,11 +557,8 @@ hipError_t krylov_iteration(Ctx* c, int it) {
         if ((e = amg_vcycle(c, c->d_p, c->d_phat)) != hipSuccess) return e;
         if (!c->comm.plans.empty() && (e = halo_exchange_plan_f32(c, c->comm.plans[0], c->d_phat)) != hipSuccess) return e;
     } else if ((e = halo_exchange(c, c->d_p)) != hipSuccess) return e;
-    {
-        PhaseTimer t(c, SHK_PH_SPMV);
-        if (amg) hipLaunchKernelGGL((k_spmv<1, float>), g, b, 0, c->stream, spmv_args(c, A, c->d_phat, c->d_v));
-        else hipLaunchKernelGGL((k_spmv<1, double>), g, b, 0, c->stream, spmv_args(c, A, c->d_p, c->d_v));
-    }
+    if (amg) launch_phase(c, SHK_PH_SPMV, k_spmv<1, float>, g, b, 0, spmv_args(c, A, c->d_phat, c->d_v));
+    else launch_phase(c, SHK_PH_SPMV, k_spmv<1, double>, g, b, 0, spmv_args(c, A, c->d_p, c->d_v));
     if ((e = allreduce_parts(c, P_RR, 2)) != hipSuccess) return e;
     {
         PhaseTimer t(c, SHK_PH_VECTOR);
@@ -575,11 +570,10 @@ hipError_t krylov_iteration(Ctx* c, int it) {
         if (!c->comm.plans.empty() && (e = halo_exchange_plan_f32(c, c->comm.plans[0], c->d_shat)) != hipSuccess) return e;
     } else if ((e = halo_exchange(c, c->d_s)) != hipSuccess) return e;
     {
-        PhaseTimer t(c, SHK_PH_SPMV);
         SpmvArgs a = spmv_args(c, A, amg ? (const void*)c->d_shat : (const void*)c->d_s, c->d_t);
         a.sdot = c->d_s;
-        if (amg) hipLaunchKernelGGL((k_spmv<2, float>), g, b, 0, c->stream, a);
-        else hipLaunchKernelGGL((k_spmv<2, double>), g, b, 0, c->stream, a);
+        if (amg) launch_phase(c, SHK_PH_SPMV, k_spmv<2, float>, g, b, 0, a);
+        else launch_phase(c, SHK_PH_SPMV, k_spmv<2, double>, g, b, 0, a);
     }
     if ((e = allreduce_parts(c, P_TS, 4)) != hipSuccess) return e;
     {
@@ -761,8 +755,7 @@ void launch_join_q(Ctx* c, double* io) {
 }
 
 // ------------------------------------------------------------------ profiling
-PhaseTimer::PhaseTimer(Ctx* c_, int phase) : c(c_) {
-    if (!c->profiling) return;
+int profile_slot(Ctx* c, int phase) {
     if (c->ev_used == c->ev_pool.size()) {
         Ctx::Ev e;
         // no system-scope fence at the events: a default event flushes / invalidates the caches around every
@@ -771,8 +764,13 @@ PhaseTimer::PhaseTimer(Ctx* c_, int phase) : c(c_) {
         (void)hipEventCreateWithFlags(&e.b, hipEventDisableSystemFence);
         c->ev_pool.push_back(e);
     }
-    idx = (int)c->ev_used++;
+    const int idx = (int)c->ev_used++;
     c->ev_pool[idx].phase = phase;
+    return idx;
+}
+PhaseTimer::PhaseTimer(Ctx* c_, int phase) : c(c_) {
+    if (!c->profiling) return;
+    idx = profile_slot(c, phase);
     (void)hipEventRecord(c->ev_pool[idx].a, c->stream);
 }
 PhaseTimer::~PhaseTimer() {
