@@ -25,7 +25,7 @@ norm = max(F.get("shk::k_norm2(long, double const*, double*)", [0.0]))
 factor = calib_bytes / (norm * 1024.0) if norm else 2.0
 res = {"fetch_size_correction": factor, "calibration": {"kernel": "k_norm2 over the SELL value array",
        "known_bytes": calib_bytes, "fetch_size_kib": norm}, "kernels": {}}
-want = {"k_amg_post<true": "amg_fine", "k_amg_first<true": "amg_first", "k_spmv<0>": "spmv_plain", "k_spmv<1>": "spmv1", "k_spmv<2>": "spmv2",
+want = {"k_amg_post<true": "amg_fine", "k_amg_first<true": "amg_first", "k_spmv<0": "spmv_plain", "k_spmv<1": "spmv1", "k_spmv<2": "spmv2",
         "k_assemble": "assemble", "k_bicg_u": "bicg_u", "k_bicg_s": "bicg_s"}
 for name in set(F) | set(W):
     for pat, key in want.items():
