@@ -43,8 +43,9 @@ _BUILD_KNOBS = dict(
     setup_file=None,            # optional path copied next to the results (solvers.py:125)
     device=0, krylov_rtol=1e-10, krylov_max_it=20000,
     preconditioner="amg",       # "amg" (default) | "amg_local" | "jacobi" (north_star's solver)
-    ingest="auto",              # where interp_data / set_lake_bdry evaluate: "device" (HIP kernels, bit-identical
-                                # to scipy) | "host" (the reference's own scipy call) | "auto" = device if a GPU is visible
+    ingest="device",            # where interp_data / set_lake_bdry evaluate: "device" (HIP kernels, bit-identical to
+                                # scipy; raises without the built library or a GPU -- there is no silent fallback) |
+                                # "host" (an explicit choice: the reference's own scipy call / the NumPy even-odd rule)
 )
 
 
@@ -83,11 +84,8 @@ class model_setup:
         self.lake_bdry.x.scatter_forward()
 
     def _ingest_on_device(self) -> bool:
-        if self.ingest not in ("auto", "device", "host"):
-            raise ValueError(f"md.ingest must be 'auto', 'device' or 'host', not {self.ingest!r}")
-        if self.ingest == "auto":
-            import torch   # device_count() does not initialise the GPU
-            return torch.cuda.device_count() > 0
+        if self.ingest not in ("device", "host"):
+            raise ValueError(f"md.ingest must be 'device' or 'host', not {self.ingest!r}")
         return self.ingest == "device"
 
     def interp_data(self, var_name, x_d, y_d, f):

@@ -12,10 +12,11 @@ from shakti_fenics_amd.params import g, rho_i, rho_w
 from shakti_fenics_amd.synthetic import bed, surface
 
 
-def initialize(comm, nx=71, ny=71, L=100e3, days=10.0 / 24.0, results_root=None):
+def initialize(comm, nx=71, ny=71, L=100e3, days=10.0 / 24.0, results_root=None, ingest="device"):
     lake_name = "Synthetic_E2"
     domain = rectangle_mesh(nx, ny, L, L, jitter=0.25, seed=1234)       # C1 of SURVEY.md 8d
     md = model_setup(comm, domain)
+    md.ingest = ingest   # "device": interp_data / set_lake_bdry on the GPU; "host": the reference's scipy path
     md.setup_name = os.path.splitext(os.path.basename(__file__))[0]
     md.setup_file = os.path.abspath(__file__)
     md.lake_name = lake_name

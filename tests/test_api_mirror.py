@@ -47,6 +47,7 @@ def test_interp_data_is_bilinear_and_returns_the_interpolator():
     md = model_setup(SerialComm(), dom)
     xg, yg = np.linspace(-3e3, 13e3, 81), np.linspace(-3e3, 11e3, 71)
     X, Y = np.meshgrid(xg, yg)
+    md.ingest = "host"   # the reference's own scipy evaluation (no GPU in this test; "device" is covered by -m gpu)
     fi = md.interp_data("z_b", xg, yg, 3.0 + 2e-3 * X - 1e-3 * Y)   # f[y, x], linear => reproduced exactly
     assert np.allclose(md.z_b.x.array, 3.0 + 2e-3 * md.x - 1e-3 * md.y, rtol=0, atol=1e-9)
     assert abs(float(fi((1000.0, 2000.0))) - (3.0 + 2.0 - 2.0)) < 1e-9
@@ -56,6 +57,7 @@ def test_point_in_polygon_and_lake_boundary():
     dom = rectangle_mesh(21, 21, 10.0, 10.0, jitter=0.0)
     md = model_setup(SerialComm(), dom)
     sq = np.array([[2.2, 2.2], [7.7, 2.2], [7.7, 7.7], [2.2, 7.7]])
+    md.ingest = "host"
     md.set_lake_bdry(sq)
     want = (md.x > 2.2) & (md.x < 7.7) & (md.y > 2.2) & (md.y < 7.7)
     assert np.array_equal(md.lake_bdry.x.array.astype(bool), want)
@@ -64,7 +66,7 @@ def test_point_in_polygon_and_lake_boundary():
 
 def test_synthetic_setup_follows_the_setup_contract(tmp_path):
     from shakti_fenics_amd.setups import setup_synthetic_cooke2 as S
-    md = S.initialize(SerialComm(), nx=21, ny=21, results_root=tmp_path)
+    md = S.initialize(SerialComm(), nx=21, ny=21, results_root=tmp_path, ingest="host")
     assert md.N_bdry == 3.7e5 and md.setup_name == "setup_synthetic_cooke2"
     assert callable(md.OutflowBoundary) and md.timesteps.size >= 2 and md.nt_save == 1
     from shakti_fenics_amd.solvers import get_bcs

@@ -90,6 +90,7 @@ def test_model_setup_ingest_device_equals_host():
     out = {}
     for mode in ("host", "device"):
         md = model_setup(world(), dom)
+        assert md.ingest == "device"   # the default: no silent host fallback
         md.ingest = mode
         interp = md.interp_data("z_b", x_d, y_d, bed)
         md.set_lake_bdry(outline)
