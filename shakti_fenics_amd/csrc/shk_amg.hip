@@ -3,11 +3,14 @@
 //
 // Hierarchy (built once on the host, shk_plan.cpp): aggregates are runs of 4 consecutive vertices of the
 // k-d order, prolongation is piecewise constant, coarse operators are Galerkin products whose sparsity is
-// fixed, so refreshing them after each assembly is one gather-sum kernel per level.  The coarsest level
-// (<= 64 rows) is inverted densely in LDS.  One V(0,2) cycle with damped Jacobi (omega = 0.7) -- on this
-// operator it needs as many BiCGStab iterations as V(1,1) and its smoothing kernels are plain SpMVs:
-//   down  k_amg_restrict   r_c = P^T r                       (no smoothing on the way down)
-//   up    k_amg_prolong    x = P e_c ;  k_amg_post x' = x + w D^-1 (r - A x), twice
+// fixed, so refreshing them after each assembly is one gather-sum kernel per level.  The hierarchy stops early
+// on a dense coarsest level (<= 4096 rows; n^3 <= 250 nnz) whose inverse is kept and applied by a GEMV.
+// One V(0, .) cycle with damped Jacobi, dampings scaled by a power-iteration estimate of lambda_max(D^-1 A):
+//   down  k_amg_restrict(4)  r_c = P^T r                     (no smoothing on the way down)
+//   up    k_amg_first        x1 = a P e + w D^-1 (r - a (A P) e)   on the precomputed A*P operator
+//         k_amg_post         x' = x + w D^-1 (r - A x):  once more on the finest level, three more times on
+//                            every coarser one (four Chebyshev-damped sweeps there: they are cheap)
+//   levels <= 4096 rows run inside one workgroup (k_amg_tail)
 // All levels use SELL-64; an aligned group of 4 slices = 256 rows contains, by construction, all 4 members
 // of each of its 64 aggregates.
 //
