@@ -369,8 +369,8 @@ static hipError_t estimate_lambda(Ctx* c, AmgHierarchy& H) {
     for (size_t l = 0; l < H.xf.size(); ++l) {
         if (l > 0 && H.lv[l].n <= 4096) break;
         const DevSell A = level_sell(c, H, l);
-        const float* vals = l == 0 ? c->d_vals32 : H.lv[l].vals;
-        const float* dinv = l == 0 ? c->d_dinv32 : H.lv[l].dinv;
+        const float* vals = l == 0 ? H.top_vals : H.lv[l].vals;
+        const float* dinv = l == 0 ? H.top_dinv : H.lv[l].dinv;
         float* xa = l == 0 ? H.x0 : H.lv[l].x;
         float* xb = l == 0 ? H.x1 : H.lv[l].x2;
         const int grid = std::min((A.nslice + 3) / 4, 2048);
@@ -418,8 +418,16 @@ static hipError_t estimate_lambda(Ctx* c, AmgHierarchy& H) {
 }
 
 // Refresh the coarse operators from the Jacobian just assembled (d_vals, d_dinv).
-hipError_t amg_numeric_setup(Ctx* c, bool refresh_dense) {
-    AmgHierarchy& H = *c->amg;
+// A context's own hierarchies sit on the float copy of its Jacobian.
+static void bind_top_to_jacobian(Ctx* c, AmgHierarchy& H) {
+    H.topA = c->sell32();
+    H.top_vals = c->d_vals32;
+    H.top_dinv = c->d_dinv32;
+}
+
+hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense) {
+    const bool primary = &H == &c->amg_local || &H == &c->amg_dist;
+    if (primary) bind_top_to_jacobian(c, H);
     // a large dense coarsest inverse (2 launches per pivot) is only rebuilt when asked to: between the Newton
     // iterations of one time step the coarsest operator barely moves, and a slightly stale inverse only makes
     // the (fixed, linear) preconditioner marginally weaker
@@ -434,9 +442,11 @@ hipError_t amg_numeric_setup(Ctx* c, bool refresh_dense) {
     if (!H.dense_valid) refresh_dense = true;
     if (refresh_dense) { H.dense_age = 0; H.its_fresh = 0; }
     PhaseTimer t(c, SHK_PH_OTHER);
-    hipLaunchKernelGGL(k_narrow, dim3(c->grid), dim3(kBlock), 0, c->stream, c->slots, c->d_vals, c->d_vals32);
-    hipLaunchKernelGGL(k_narrow, dim3(small_grid(c->n_own)), dim3(kBlock), 0, c->stream, c->n_own, c->d_dinv, c->d_dinv32);
-    const float* fine = c->d_vals32;
+    if (primary) {
+        hipLaunchKernelGGL(k_narrow, dim3(c->grid), dim3(kBlock), 0, c->stream, c->slots, c->d_vals, c->d_vals32);
+        hipLaunchKernelGGL(k_narrow, dim3(small_grid(c->n_own)), dim3(kBlock), 0, c->stream, c->n_own, c->d_dinv, c->d_dinv32);
+    }
+    const float* fine = H.top_vals;
     for (size_t l = 0; l < H.xf.size(); ++l) {
         const AmgXfer& X = H.xf[l];
         if (X.with_ap)
@@ -476,7 +486,7 @@ hipError_t amg_numeric_setup(Ctx* c, bool refresh_dense) {
 }
 
 static DevSell level_sell(const Ctx* c, const AmgHierarchy& H, size_t l) {
-    if (l == 0) return c->sell32();
+    if (l == 0) return H.topA;
     const AmgLevel& L = H.lv[l];
     return DevSell{L.n, L.n_cols, L.nslice, sell_fits_cache(L.slots, kAmgSlotBytes), L.ptr, L.col, L.rowlen, L.cbase,
                    L.ptr16, L.col16};
@@ -505,11 +515,10 @@ __global__ __launch_bounds__(kBlock) void k_amg_restrict4(int32_t n, const doubl
 }
 
 // Tables of the four-level restriction for the active hierarchy (nlev = 0: unavailable).
-static RestrictArgs amg_restrict_args(const Ctx* c) {
+static RestrictArgs amg_restrict_args(const AmgHierarchy& H) {
     static const bool enabled = !(getenv("SHK_FUSED_RESTRICT") && atoi(getenv("SHK_FUSED_RESTRICT")) == 0);
     RestrictArgs ra{};
-    if (!c->use_amg || !c->amg || !enabled || c->n_own > ((int64_t)1 << 21)) return ra;
-    const AmgHierarchy& H = *c->amg;
+    if (!enabled || H.topA.n_rows > (1 << 21)) return ra;
     const size_t lt = tail_start(H);
     for (size_t l = 0; l < lt && l < (size_t)kFusedRestrict; ++l) {
         const AmgXfer& X = H.xf[l];
@@ -533,8 +542,8 @@ static void launch_post(Ctx* c, const DevSell& A, const float* vals, const float
 }
 
 // z = M^-1 r : one V(0,2) cycle.  r and z have the fine level's length; r is not modified.
-hipError_t amg_vcycle(Ctx* c, const double* rin, float* zout) {
-    AmgHierarchy& H = *c->amg;
+hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
+    const int32_t n_top = H.topA.n_rows, ncol_top = H.topA.n_cols;
     const size_t nx = H.xf.size();  // levels 0..nx-1 are sparse, level nx is the dense coarsest
     const int* done = &c->d_state->done;
     static const double fw1 = getenv("SHK_AMG_W1") ? atof(getenv("SHK_AMG_W1")) : 0.0;   // experiment overrides
@@ -543,20 +552,20 @@ hipError_t amg_vcycle(Ctx* c, const double* rin, float* zout) {
     const float alpha = (float)H.alpha, omega = w1;
     hipError_t e;
     const size_t lt = tail_start(H);
-    if (c->n_loc > c->n_own && !(H.distributed && H.halo_levels > 0)) {
+    if (ncol_top > n_top && !(H.distributed && H.halo_levels > 0)) {
         // block-local smoothing on the finest level: the output vector's ghost entries (left over from the Krylov
         // loop's own exchange) must read as zero, or the preconditioner would change from call to call
-        if ((e = hipMemsetAsync(zout + c->n_own, 0, (size_t)(c->n_loc - c->n_own) * sizeof(float), c->stream)) != hipSuccess)
+        if ((e = hipMemsetAsync(zout + n_top, 0, (size_t)(ncol_top - n_top) * sizeof(float), c->stream)) != hipSuccess)
             return e;
     }
     {
         PhaseTimer t(c, SHK_PH_AMG_COARSE);
-        const RestrictArgs ra = amg_restrict_args(c);
+        const RestrictArgs ra = amg_restrict_args(H);
         // one launch for four levels while a workgroup has few groups to walk through (each costs a memory round
         // trip and four barriers); measured at 1M rows: 46.9 -> 45.4 ms/step, at 10M rows the plain cascade wins
         if (ra.nlev > 1)
-            hipLaunchKernelGGL(k_amg_restrict4, dim3(std::min((int)((c->n_own + kBlock - 1) / kBlock), 2048)), dim3(kBlock),
-                               0, c->stream, (int32_t)c->n_own, rin, ra, done);
+            hipLaunchKernelGGL(k_amg_restrict4, dim3(std::min((n_top + kBlock - 1) / kBlock, 2048)), dim3(kBlock),
+                               0, c->stream, n_top, rin, ra, done);
         for (size_t l = ra.nlev > 1 ? (size_t)ra.nlev : 0; l < lt; ++l) {
             const AmgXfer& X = H.xf[l];
             float* rc = X.dense ? H.cr : H.lv[l + 1].r;
@@ -617,7 +626,7 @@ hipError_t amg_vcycle(Ctx* c, const double* rin, float* zout) {
             if (fused) {
                 AmgFirstArgs<double> f{DevSell{X.n_fine, X.n_coarse_cols, X.ap_nslice, sell_fits_cache(X.ap_slots, kAmgSlotBytes),
                                                X.ap_ptr, X.ap_col, X.ap_rowlen, X.ap_cbase, X.ap_ptr16, X.ap_col16},
-                                       X.ap_vals, c->d_dinv32, rin, ec, X.agg, H.x0, omega, alpha, done};
+                                       X.ap_vals, H.top_dinv, rin, ec, X.agg, H.x0, omega, alpha, done};
                 launch_phase(c, SHK_PH_AMG_FIRST, k_amg_first<true, double>, g, dim3(kBlock), 0, f);
             } else {
                 {
@@ -626,10 +635,10 @@ hipError_t amg_vcycle(Ctx* c, const double* rin, float* zout) {
                                        X.n_fine, alpha, X.agg, ec, zout, done);
                 }
                 if (halo && (e = halo_exchange_plan_f32(c, *HP, zout)) != hipSuccess) return e;
-                launch_post<true>(c, A, c->d_vals32, c->d_dinv32, rin, (const float*)zout, H.x0, w1, done);
+                launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)zout, H.x0, w1, done);
             }
             if (halo && (e = halo_exchange_plan_f32(c, *HP, H.x0)) != hipSuccess) return e;
-            launch_post<true>(c, A, c->d_vals32, c->d_dinv32, rin, (const float*)H.x0, zout, w2, done);
+            launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)H.x0, zout, w2, done);
         } else {
             const AmgLevel& L = H.lv[l];
             // coarse levels are cheap next to the finest one, and a better coarse solve pays: four sweeps with the

@@ -565,7 +565,7 @@ static int read_aux_norm(Ctx* c, double* out) {  // fixed-order host sum of the 
 // residual, and the correction equation is solved again if the target was missed.
 static int krylov_solve(Ctx* c, int* its, int* converged, double* relres, bool first_of_step = true) {
     if (c->use_amg) {
-        HIPCHK(amg_numeric_setup(c, first_of_step));   // Galerkin coarse operators of the Jacobian just assembled
+        HIPCHK(amg_numeric_setup(c, *c->amg, first_of_step));   // Galerkin coarse operators of the Jacobian just assembled
     } else {
         HIPCHK(halo_exchange(c, c->d_dinv));  // ghost columns of A' = A D^-1 need their owners' diagonal
         launch_scale(c);

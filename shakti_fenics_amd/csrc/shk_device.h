@@ -314,6 +314,10 @@ struct AmgXfer {  // level l -> l+1
 // context: no communication) or distributed (ghost columns kept on every level, per-level halo plans, one
 // dense coarsest operator shared by all subdomains).
 struct AmgHierarchy {
+    // The operator the hierarchy sits on ("level 0"): the Jacobian's float copy for a context's own hierarchies
+    // (bound by amg_bind_top before use), or the gathered global level of a replicated coarse hierarchy.
+    DevSell topA{};
+    const float *top_vals = nullptr, *top_dinv = nullptr;
     std::vector<AmgLevel> lv;    // [0] unused, [l] = sparse coarse level l
     std::vector<AmgXfer> xf;     // [l] : level l -> l+1; the last one lands on the dense coarsest level
     std::vector<int> plan_of;    // distributed: index into Comm::plans of level l's halo plan (size = xf.size())
@@ -484,8 +488,8 @@ hipError_t halo_exchange_plan(Ctx* c, const HaloPlan& P, double* vec);
 hipError_t halo_exchange_plan_f32(Ctx* c, const HaloPlan& P, float* vec);
 hipError_t allreduce_buffer(Ctx* c, const double* src, double* dst, size_t n);  // element-wise sum over subdomains
 int amg_setup_distributed(Ctx* c, std::string& err);  // collective
-hipError_t amg_numeric_setup(Ctx* c, bool refresh_dense);
-hipError_t amg_vcycle(Ctx* c, const double* rin, float* zout);
+hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense);
+hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout);
 // upload one host hierarchy (shk_api.hip: owns the allocation helpers)
 hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H, int64_t n_loc0);
 hipError_t allreduce_parts(Ctx* c, int first, int nslots);

@@ -554,7 +554,7 @@ hipError_t krylov_iteration(Ctx* c, int it) {
     const double* A = c->use_amg ? c->d_vals : c->d_vals_s;
     const bool amg = c->use_amg;
     if (amg) {
-        if ((e = amg_vcycle(c, c->d_p, c->d_phat)) != hipSuccess) return e;
+        if ((e = amg_vcycle(c, *c->amg, c->d_p, c->d_phat)) != hipSuccess) return e;
         if (!c->comm.plans.empty() && (e = halo_exchange_plan_f32(c, c->comm.plans[0], c->d_phat)) != hipSuccess) return e;
     } else if ((e = halo_exchange(c, c->d_p)) != hipSuccess) return e;
     if (amg) launch_phase(c, SHK_PH_SPMV, k_spmv<1, float>, g, b, 0, spmv_args(c, A, c->d_phat, c->d_v));
@@ -566,7 +566,7 @@ hipError_t krylov_iteration(Ctx* c, int it) {
                            c->cur_atol2, c->np, c->d_red, part, c->d_r, c->d_v, c->d_rhat, c->d_s, c->d_state);
     }
     if (amg) {
-        if ((e = amg_vcycle(c, c->d_s, c->d_shat)) != hipSuccess) return e;
+        if ((e = amg_vcycle(c, *c->amg, c->d_s, c->d_shat)) != hipSuccess) return e;
         if (!c->comm.plans.empty() && (e = halo_exchange_plan_f32(c, c->comm.plans[0], c->d_shat)) != hipSuccess) return e;
     } else if ((e = halo_exchange(c, c->d_s)) != hipSuccess) return e;
     {
