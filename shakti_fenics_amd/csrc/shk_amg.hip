@@ -19,6 +19,7 @@
 // half the bytes.  BiCGStab's own vectors, its operator, the true-residual refinement and the dense coarsest
 // solve stay in double; the recurrence uses p^ = M^-1 p exactly as computed, so rounding inside M^-1 changes
 // (marginally) the iteration count, never the solution the stopping test certifies.
+#include <climits>
 #include <cmath>
 #include <cstdio>
 
@@ -93,7 +94,8 @@ __global__ __launch_bounds__(kBlock) void k_dense_invert(int n, const double* __
 __global__ __launch_bounds__(kBlock) void k_coarse_scatter(int n, int row0, int ncols, const float* __restrict__ rc,
                                                            double* __restrict__ rglob, const int* __restrict__ done) {
     if (*done) return;
-    for (int j = threadIdx.x; j < ncols; j += kBlock) rglob[j] = (j >= row0 && j < row0 + n) ? (double)rc[j - row0] : 0.0;
+    for (int j = blockIdx.x * kBlock + threadIdx.x; j < ncols; j += gridDim.x * kBlock)
+        rglob[j] = (j >= row0 && j < row0 + n) ? (double)rc[j - row0] : 0.0;
 }
 
 // Gauss-Jordan inverse of a dense coarsest operator with 64 < n <= 1024 rows, in global memory (L2-resident):
@@ -397,6 +399,10 @@ static hipError_t estimate_lambda(Ctx* c, AmgHierarchy& H) {
         for (int b = 0; b < grid; ++b) { so += h[b]; sx += h[kMaxParts + b]; }
         if (sx > 0.0 && std::isfinite(so)) lam = std::max(lam, std::sqrt(so / sx));
         // (the scratch vectors' ghost columns are still zero, and every V-cycle overwrites their owned rows first)
+        // The two partial arrays go back to zero: a replicated global level can have more row groups than this
+        // subdomain's own grid, and entries beyond that grid must stay zero for the reductions across subdomains.
+        if ((e = hipMemsetAsync(c->d_part + (size_t)P_AUX * kMaxParts, 0, 2 * (size_t)kMaxParts * sizeof(double), c->stream)) != hipSuccess)
+            return e;
     }
     // subdomains must agree on the damping: take the largest estimate
     if (c->comm.kind != Comm::NONE && c->comm.nranks > 1) {
@@ -425,22 +431,26 @@ static void bind_top_to_jacobian(Ctx* c, AmgHierarchy& H) {
     H.top_dinv = c->d_dinv32;
 }
 
-hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense) {
+hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense, bool decided) {
     const bool primary = &H == &c->amg_local || &H == &c->amg_dist;
     if (primary) bind_top_to_jacobian(c, H);
     // a large dense coarsest inverse (2 launches per pivot) is only rebuilt when asked to: between the Newton
     // iterations of one time step the coarsest operator barely moves, and a slightly stale inverse only makes
     // the (fixed, linear) preconditioner marginally weaker
     // ... and across time steps: a big inverse (> 512 rows) is rebuilt every `dense_period`-th request, or at
-    // once when the last solve needed 25 % more iterations than the first one after the previous rebuild
-    const AmgXfer& XD = H.xf.back();
-    const int nd = H.distributed ? H.n_glob : XD.n_coarse;
-    if (refresh_dense && H.dense_valid && nd > 512) {
-        const bool degraded = H.its_fresh > 0 && H.its_last > 1.25 * H.its_fresh;
-        if (++H.dense_age < H.dense_period && !degraded) refresh_dense = false;
+    // once when the last solve needed 25 % more iterations than the first one after the previous rebuild.
+    // (With a replicated coarse part the dense level lives in `rep`; the iteration feedback stays with H.)
+    if (!decided) {
+        AmgHierarchy& D = H.rep ? *H.rep : H;
+        const AmgXfer& XD = D.xf.back();
+        const int nd = D.distributed ? D.n_glob : XD.n_coarse;
+        if (refresh_dense && D.dense_valid && nd > 512) {
+            const bool degraded = H.its_fresh > 0 && H.its_last > 1.25 * H.its_fresh;
+            if (++D.dense_age < D.dense_period && !degraded) refresh_dense = false;
+        }
+        if (!D.dense_valid) refresh_dense = true;
+        if (refresh_dense) { D.dense_age = 0; H.its_fresh = 0; }
     }
-    if (!H.dense_valid) refresh_dense = true;
-    if (refresh_dense) { H.dense_age = 0; H.its_fresh = 0; }
     PhaseTimer t(c, SHK_PH_OTHER);
     if (primary) {
         hipLaunchKernelGGL(k_narrow, dim3(c->grid), dim3(kBlock), 0, c->stream, c->slots, c->d_vals, c->d_vals32);
@@ -452,7 +462,20 @@ hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense) {
         if (X.with_ap)
             hipLaunchKernelGGL(k_galerkin<float>, dim3(small_grid(X.ap_slots)), dim3(kBlock), 0, c->stream, X.ap_slots,
                                X.ap_gptr, X.ap_glist, fine, X.ap_vals);
-        if (X.dense) {
+        if (X.onto_global) {
+            // my rows of the replicated global level (zeros elsewhere), completed by one all-reduce; then the
+            // replicated hierarchy refreshes itself from it, identically on every subdomain
+            AmgHierarchy& R = *H.rep;
+            hipLaunchKernelGGL(k_galerkin<double>, dim3(small_grid(R.t_slots)), dim3(kBlock), 0, c->stream, R.t_slots,
+                               X.gptr, X.glist, fine, H.rep_gtmp);
+            hipError_t e = allreduce_buffer(c, H.rep_gtmp, H.rep_gtmp, (size_t)R.t_slots);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(k_narrow, dim3(small_grid(R.t_slots)), dim3(kBlock), 0, c->stream, R.t_slots,
+                               (const double*)H.rep_gtmp, R.t_vals);
+            hipLaunchKernelGGL(k_diag_inv, dim3(small_grid(H.rep_n)), dim3(kBlock), 0, c->stream, H.rep_n, R.t_diag,
+                               (const float*)R.t_vals, R.t_dinv);
+            if ((e = amg_numeric_setup(c, R, refresh_dense, true)) != hipSuccess) return e;
+        } else if (X.dense) {
             const int64_t ns = (int64_t)X.n_coarse * X.n_coarse_cols;  // my rows of the coarsest operator
             if (H.distributed) {
                 const size_t all = (size_t)H.n_glob * H.n_glob;
@@ -525,7 +548,7 @@ static RestrictArgs amg_restrict_args(const AmgHierarchy& H) {
         if (!X.members_kd || !X.kd_pos) break;
         ra.members[l] = reinterpret_cast<const int4*>(X.members_kd);
         ra.pos[l] = X.kd_pos;
-        ra.rc[l] = X.dense ? H.cr : H.lv[l + 1].r;
+        ra.rc[l] = X.dense ? H.cr : X.onto_global ? H.rep_rloc : H.lv[l + 1].r;
         ra.nc[l] = X.n_coarse;
         ra.nlev = (int)l + 1;
     }
@@ -549,9 +572,9 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
     static const double fw1 = getenv("SHK_AMG_W1") ? atof(getenv("SHK_AMG_W1")) : 0.0;   // experiment overrides
     static const double fw2 = getenv("SHK_AMG_W2") ? atof(getenv("SHK_AMG_W2")) : 0.0;
     const float w1 = (float)(fw1 > 0.0 ? fw1 : H.c1 / H.lambda), w2 = (float)(fw2 > 0.0 ? fw2 : H.c2 / H.lambda);
-    const float alpha = (float)H.alpha, omega = w1;
+    const float alpha = (float)H.alpha;
     hipError_t e;
-    const size_t lt = tail_start(H);
+    const size_t lt = H.rep ? nx : tail_start(H);   // a replicated coarse part takes over after the last launch level
     if (ncol_top > n_top && !(H.distributed && H.halo_levels > 0)) {
         // block-local smoothing on the finest level: the output vector's ghost entries (left over from the Krylov
         // loop's own exchange) must read as zero, or the preconditioner would change from call to call
@@ -568,7 +591,7 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
                                0, c->stream, n_top, rin, ra, done);
         for (size_t l = ra.nlev > 1 ? (size_t)ra.nlev : 0; l < lt; ++l) {
             const AmgXfer& X = H.xf[l];
-            float* rc = X.dense ? H.cr : H.lv[l + 1].r;
+            float* rc = X.dense ? H.cr : X.onto_global ? H.rep_rloc : H.lv[l + 1].r;
             const dim3 g(small_grid(X.n_coarse));
             if (l == 0)
                 hipLaunchKernelGGL(k_amg_restrict<double>, g, dim3(kBlock), 0, c->stream, X.n_coarse, X.members, rin, rc, done);
@@ -578,6 +601,17 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
         }
     }
     const AmgXfer& XL = H.xf[nx - 1];
+    if (H.rep) {
+        // gather the replicated level's right-hand side (my rows, zeros elsewhere, one all-reduce) and run the rest
+        // of the cycle redundantly on every subdomain
+        {
+            PhaseTimer t(c, SHK_PH_AMG_COARSE);
+            hipLaunchKernelGGL(k_coarse_scatter, dim3(small_grid(H.rep_n)), dim3(kBlock), 0, c->stream, XL.n_coarse,
+                               H.rep_row0, H.rep_n, H.rep_rloc, H.rep_rglob, done);
+        }
+        if ((e = allreduce_buffer(c, H.rep_rglob, H.rep_rglob, (size_t)H.rep_n)) != hipSuccess) return e;
+        if ((e = amg_vcycle(c, *H.rep, H.rep_rglob, H.rep_xglob)) != hipSuccess) return e;
+    }
     TailArgs ta;
     ta.nlev = (int)(nx - lt);
     for (size_t l = lt; l < nx; ++l) {
@@ -590,7 +624,9 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
     ta.omega = w1; ta.omega2 = w2; ta.alpha = alpha; ta.done = done;
     ta.dense_in_tail = ta.ncols <= 128 ? 1 : 0;
     const int gemv_grid = std::min(2048, (ta.n_c + 3) / 4);
-    if (H.distributed) {
+    if (H.rep) {
+        // (done above)
+    } else if (H.distributed) {
         {
             PhaseTimer t(c, SHK_PH_AMG_COARSE);
             if (ta.nlev > 0) hipLaunchKernelGGL(k_amg_tail<1>, dim3(1), dim3(kTailThreads), 0, c->stream, ta);
@@ -615,14 +651,19 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
     }
     for (size_t l = lt; l-- > 0;) {
         const AmgXfer& X = H.xf[l];
-        const float* ec = X.dense ? H.cx : H.lv[l + 1].x2;
+        const float* ec = X.dense ? H.cx : X.onto_global ? H.rep_xglob + H.rep_row0 : H.lv[l + 1].x2;
         const bool fused = X.with_ap && !H.distributed;
         const bool halo = H.distributed && (int)l < H.halo_levels;
         const HaloPlan* HP = halo ? &c->comm.plans[H.plan_of[l]] : nullptr;
         const DevSell A = level_sell(c, H, l);
         const dim3 g(std::min((A.nslice + 3) / 4, 2048));
         if (l == 0) {
-            // level 0: right-hand side = the Krylov vector (double); the iterate and the result are float
+            // level 0: right-hand side = the Krylov vector (double); the iterate and the result are float.
+            // A replicated hierarchy's top level is a coarse level of the whole cycle: four sweeps, like its peers.
+            const float w2_fine = w2;
+            const bool four = H.top_four && H.coarse4;
+            const float omega = four ? (float)(H.c4[0] / H.lambda) : w1;
+            const float w2 = four ? (float)(H.c4[1] / H.lambda) : w2_fine;
             if (fused) {
                 AmgFirstArgs<double> f{DevSell{X.n_fine, X.n_coarse_cols, X.ap_nslice, sell_fits_cache(X.ap_slots, kAmgSlotBytes),
                                                X.ap_ptr, X.ap_col, X.ap_rowlen, X.ap_cbase, X.ap_ptr16, X.ap_col16},
@@ -635,10 +676,14 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
                                        X.n_fine, alpha, X.agg, ec, zout, done);
                 }
                 if (halo && (e = halo_exchange_plan_f32(c, *HP, zout)) != hipSuccess) return e;
-                launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)zout, H.x0, w1, done);
+                launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)zout, H.x0, omega, done);
             }
             if (halo && (e = halo_exchange_plan_f32(c, *HP, H.x0)) != hipSuccess) return e;
             launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)H.x0, zout, w2, done);
+            if (four) {
+                launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)zout, H.x0, (float)(H.c4[2] / H.lambda), done);
+                launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)H.x0, zout, (float)(H.c4[3] / H.lambda), done);
+            }
         } else {
             const AmgLevel& L = H.lv[l];
             // coarse levels are cheap next to the finest one, and a better coarse solve pays: four sweeps with the
@@ -711,6 +756,26 @@ static hipError_t allgather_int(Ctx* c, int32_t mine, std::vector<int32_t>& all)
     return hipSuccess;
 }
 
+// Concatenation over subdomains of integer arrays (mine at [my_off, my_off + mine.size()) of `total`), through one
+// all-reduce of a zero-padded double array on a temporary device buffer.  Setup-time only.
+static hipError_t allgather_i32(Ctx* c, const std::vector<int32_t>& mine, int64_t my_off, int64_t total,
+                                std::vector<int32_t>& all) {
+    std::vector<double> buf((size_t)std::max<int64_t>(total, 1), 0.0);
+    for (size_t i = 0; i < mine.size(); ++i) buf[(size_t)my_off + i] = (double)mine[i];
+    double* d = nullptr;
+    hipError_t e = hipMalloc((void**)&d, buf.size() * sizeof(double));
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(d, buf.data(), buf.size() * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = allreduce_buffer(c, d, d, buf.size());
+    if (e == hipSuccess) e = hipMemcpyAsync(buf.data(), d, buf.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return e;
+    all.resize((size_t)total);
+    for (int64_t i = 0; i < total; ++i) all[(size_t)i] = (int32_t)buf[(size_t)i];
+    return hipSuccess;
+}
+
 // Build the distributed hierarchy: aggregates are local (runs of 4 owned rows in k-d order), but every level
 // keeps its ghost columns (the neighbours' aggregates), so the Galerkin operators are exactly those of the
 // undecomposed matrix and a V-cycle with per-level ghost exchanges is the same operator as on one GPU.
@@ -724,6 +789,14 @@ int amg_setup_distributed(Ctx* c, std::string& err) {
     AmgHierarchy& H = c->amg_dist;
     H.distributed = true;
     if (const char* s = getenv("SHK_AMG_HALO_LEVELS")) H.halo_levels = std::max(0, atoi(s));
+    // first level gathered and replicated on every subdomain: the first whose global size is at most this (0: never)
+    // (default 200 000: level 3 of a 10M-row mesh, level 2 at 1M rows; the gathered right-hand side is then at most
+    // 1.6 MB per cycle.  Rehearsed with 4 | 5 subdomains at 10M rows: 48 | 56 iterations per Newton iteration, the same
+    // as with every level exchanging ghosts, against 76 | 86 with two exchanging levels and block-local ones below.)
+    int64_t rep_rows = 200000;
+    if (const char* s = getenv("SHK_AMG_REP_ROWS")) rep_rows = std::max(0, atoi(s));
+    SellPattern G;                       // the replicated global level, if any
+    std::vector<int32_t> G_diag;
     std::vector<AmgLevelPlan> plans;
     plans.reserve(40);
     const SellPattern* Af = &c->plan.A;
@@ -752,6 +825,15 @@ int amg_setup_distributed(Ctx* c, std::string& err) {
         }
         const bool next_dense = maxnc <= per_rank_dense;
         if (next_dense && offs[R] > 4608) { err = "shared coarsest level too large (too many subdomains)"; return -1; }
+        const bool next_rep = !next_dense && rep_rows > 0 && (int64_t)offs[R] <= rep_rows && offs[R] > 4096;
+        const bool glob_cols = next_dense || next_rep;   // the next level's columns are global row ids
+        if (next_rep) {
+            // Every subdomain's block of the replicated level starts at a multiple of 4^5 (dummy identity rows fill
+            // the gap): the replicated hierarchy aggregates runs of 4 GLOBAL rows level after level, and only an
+            // aligned block keeps those runs inside the subdomain's own k-d cells (unaligned, every aggregate
+            // straddles two cells and the cycle needs twice the iterations).
+            for (int r = 0; r < R; ++r) offs[r + 1] = offs[r] + ((all_nc[r] + 1023) / 1024) * 1024;
+        }
         const int32_t nc_own = all_nc[me];
         const HaloPlan& P = m.plans[cur_plan];
         std::vector<int32_t> gagg;
@@ -764,7 +846,7 @@ int amg_setup_distributed(Ctx* c, std::string& err) {
         CP.send_ptr.assign(1, 0);
         CP.recv_ptr.assign(1, 0);
         std::vector<int32_t> colmap((size_t)(n_own + n_ghost), -1);
-        for (int64_t i = 0; i < n_own; ++i) colmap[i] = next_dense ? offs[me] + agg[i] : agg[i];
+        for (int64_t i = 0; i < n_own; ++i) colmap[i] = glob_cols ? offs[me] + agg[i] : agg[i];
         int64_t cghost = 0;
         for (size_t k = 0; k < P.nbr.size(); ++k) {
             std::vector<int32_t> ids(gagg.begin() + P.recv_ptr[k], gagg.begin() + P.recv_ptr[k + 1]);
@@ -773,7 +855,7 @@ int amg_setup_distributed(Ctx* c, std::string& err) {
             for (int64_t g = P.recv_ptr[k]; g < P.recv_ptr[k + 1]; ++g) {
                 if (gagg[g] < 0 || gagg[g] >= all_nc[P.nbr[k]]) { err = "inconsistent aggregate id from a neighbour"; return -1; }
                 const int32_t pos = (int32_t)(std::lower_bound(ids.begin(), ids.end(), gagg[g]) - ids.begin());
-                colmap[n_own + g] = next_dense ? offs[P.nbr[k]] + gagg[g] : (int32_t)(nc_own + cghost + pos);
+                colmap[n_own + g] = glob_cols ? offs[P.nbr[k]] + gagg[g] : (int32_t)(nc_own + cghost + pos);
             }
             cghost += (int64_t)ids.size();
             CP.recv_ptr.push_back(cghost);
@@ -785,10 +867,38 @@ int amg_setup_distributed(Ctx* c, std::string& err) {
             CP.send_ptr.push_back((int64_t)CP.h_send_idx.size());
         }
         plans.emplace_back();
-        const int32_t ncols = next_dense ? offs[R] : (int32_t)(nc_own + cghost);
-        std::string perr = coarsen(*Af, agg, colmap, nc_own, ncols, next_dense, plans.back());
+        const int32_t ncols = glob_cols ? offs[R] : (int32_t)(nc_own + cghost);
+        std::string perr;
+        if (next_rep) {
+            // every subdomain contributes the rows it owns of the global level; all of them assemble its pattern
+            const int32_t nblk = offs[me + 1] - offs[me];   // my block: nc_own real rows, then dummy identity rows
+            std::vector<int32_t> rp, ci, len(nblk, 1), all_len, all_ci, all_nnz;
+            perr = coarse_rows(*Af, agg, colmap, nc_own, offs[me], rp, ci);
+            if (!perr.empty()) { err = perr; return -1; }
+            for (int32_t I = 0; I < nc_own; ++I) len[I] = rp[I + 1] - rp[I];
+            for (int32_t I = nc_own; I < nblk; ++I) ci.push_back(offs[me] + I);
+            if ((e = allgather_int(c, (int32_t)ci.size(), all_nnz)) != hipSuccess) { err = hipGetErrorString(e); return -1; }
+            int64_t nnz_off = 0, nnz_tot = 0;
+            for (int r = 0; r < R; ++r) { if (r < me) nnz_off += all_nnz[r]; nnz_tot += all_nnz[r]; }
+            if (nnz_tot > INT32_MAX) { err = "replicated level too large"; return -1; }
+            if ((e = allgather_i32(c, len, offs[me], offs[R], all_len)) != hipSuccess ||
+                (e = allgather_i32(c, ci, nnz_off, nnz_tot, all_ci)) != hipSuccess) { err = hipGetErrorString(e); return -1; }
+            std::vector<int32_t> grp((size_t)offs[R] + 1, 0);
+            for (int32_t I = 0; I < offs[R]; ++I) grp[I + 1] = grp[I] + all_len[I];
+            if (grp[offs[R]] != (int32_t)nnz_tot) { err = "replicated level: inconsistent row lengths"; return -1; }
+            // rows arrive with their diagonal first, in global ids; sell_from_csr wants the diagonal to be the row id
+            perr = sell_from_csr(offs[R], offs[R], grp, all_ci, G, G_diag);
+            if (perr.empty()) perr = coarsen_onto_global(*Af, agg, colmap, nc_own, offs[me], G, plans.back());
+        } else {
+            perr = coarsen(*Af, agg, colmap, nc_own, ncols, next_dense, plans.back());
+        }
         if (!perr.empty()) { err = perr; return -1; }
         H.plan_of.push_back((int)cur_plan);
+        if (next_rep) {
+            H.rep_row0 = offs[me];
+            H.rep_n = offs[R];
+            break;
+        }
         if (next_dense) {
             H.n_glob = offs[R];
             H.offset = offs[me];
@@ -813,6 +923,22 @@ int amg_setup_distributed(Ctx* c, std::string& err) {
         for (int64_t I = 0; I < n_own; ++I) agg[I] = (int32_t)(I / 4);
     }
     if ((e = amg_upload(c, plans, H, c->n_loc)) != hipSuccess) { err = hipGetErrorString(e); return -1; }
+    if (H.rep_n > 0) {
+        // the rest of the hierarchy: a single-GPU one on the global level, built identically by every subdomain
+        // (aggregates = runs of 4 global rows: rows of one subdomain are consecutive and in its k-d order)
+        std::vector<int32_t> ident((size_t)G.n_rows);
+        for (int32_t i = 0; i < G.n_rows; ++i) ident[i] = i;
+        PlanOptions opt;
+        if (const char* s = getenv("SHK_AMG_COARSEST")) opt.amg_coarsest = atoi(s);
+        opt.amg_cost_nnz = (double)c->nnz * R;   // the dense level is sized against the whole fine operator
+        std::vector<AmgLevelPlan> rplans;
+        std::string perr = build_amg_levels(G, ident, opt, rplans);
+        if (!perr.empty() || rplans.empty()) { err = perr.empty() ? "replicated level too small for a hierarchy" : perr; return -1; }
+        H.rep = new AmgHierarchy();
+        H.rep->top_four = true;
+        if ((e = amg_upload_rep_top(c, *H.rep, G, G_diag)) != hipSuccess ||
+            (e = amg_upload(c, rplans, *H.rep, G.n_rows, &ident)) != hipSuccess) { err = hipGetErrorString(e); return -1; }
+    }
     return 0;
 }
 

@@ -102,7 +102,29 @@ static void set_poly_rule(Ctx* c) {
 }
 
 namespace shk {
-hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H, int64_t n_loc0) {
+hipError_t amg_upload_rep_top(Ctx* c, AmgHierarchy& R, const SellPattern& G, const std::vector<int32_t>& diag_slot) {
+    hipError_t e;
+    if ((e = upload(c, &R.t_ptr, G.ptr)) != hipSuccess) return e;
+    if ((e = upload(c, &R.t_col, G.col)) != hipSuccess) return e;
+    if ((e = upload(c, &R.t_rowlen, G.rowlen)) != hipSuccess) return e;
+    if ((e = upload(c, &R.t_cbase, G.cbase)) != hipSuccess) return e;
+    if ((e = upload(c, &R.t_ptr16, G.ptr16)) != hipSuccess) return e;
+    if ((e = upload(c, &R.t_col16, G.col16)) != hipSuccess) return e;
+    if ((e = upload(c, &R.t_diag, diag_slot)) != hipSuccess) return e;
+    R.t_slots = G.slots;
+    if ((e = dev_alloc(c, &R.t_vals, (size_t)G.slots)) != hipSuccess) return e;
+    if ((e = dev_alloc(c, &R.t_dinv, (size_t)G.nslice * kSlice)) != hipSuccess) return e;
+    if ((e = hipMemset(R.t_dinv, 0, (size_t)G.nslice * kSlice * sizeof(float))) != hipSuccess) return e;
+    R.topA = DevSell{G.n_rows, G.n_cols, G.nslice, sell_fits_cache(G.slots, kAmgSlotBytes), R.t_ptr, R.t_col, R.t_rowlen,
+                     R.t_cbase, R.t_ptr16, R.t_col16};
+    R.top_vals = R.t_vals;
+    R.top_dinv = R.t_dinv;
+    return hipSuccess;
+}
+
+hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H, int64_t n_loc0,
+                      const std::vector<int32_t>* krank0) {
+    const std::vector<int32_t>& kr0 = krank0 ? *krank0 : c->plan.krank;
     hipError_t e;
     const size_t nx = plans.size();
     H.xf.resize(nx);
@@ -112,6 +134,7 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
         AmgLevelPlan& LP = plans[l];
         AmgXfer& X = H.xf[l];
         X.n_fine = LP.n_fine; X.n_coarse = LP.n_coarse; X.n_coarse_cols = LP.n_coarse_cols; X.dense = LP.dense;
+        X.onto_global = LP.onto_global;
         if ((e = upload(c, &X.agg, LP.agg)) != hipSuccess) return e;
         if ((e = upload(c, &X.members, LP.members)) != hipSuccess) return e;
         if ((e = upload(c, &X.gptr, LP.gptr)) != hipSuccess) return e;
@@ -133,7 +156,7 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
                     if (m < 0) continue;
                     if (m / 256 != k / 64) ok = false;
                     // ... and the member's own k-d rank must be one of 4k .. 4k+3
-                    const int32_t mr = l == 0 ? ((size_t)m < c->plan.krank.size() ? c->plan.krank[m] : -1)
+                    const int32_t mr = l == 0 ? ((size_t)m < kr0.size() ? kr0[m] : -1)
                                               : (prev_pos.empty() ? m : prev_rank[m]);
                     if (mr / 4 != k) ok = false;
                 }
@@ -160,7 +183,13 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
             if ((e = upload(c, &X.ap_glist, LP.ap_glist)) != hipSuccess) return e;
             if ((e = dev_alloc(c, &X.ap_vals, (size_t)X.ap_slots)) != hipSuccess) return e;
         }
-        if (!LP.dense) {
+        if (LP.onto_global) {
+            if (l + 1 != nx) return hipErrorInvalidValue;  // the replicated level ends the distributed part
+            if ((e = dev_alloc(c, &H.rep_rloc, std::max<size_t>(64, (size_t)LP.n_coarse))) != hipSuccess) return e;
+            if ((e = dev_alloc(c, &H.rep_rglob, std::max<size_t>(64, (size_t)LP.n_coarse_cols))) != hipSuccess) return e;
+            if ((e = dev_alloc(c, &H.rep_xglob, std::max<size_t>(64, (size_t)LP.n_coarse_cols))) != hipSuccess) return e;
+            if ((e = dev_alloc(c, &H.rep_gtmp, LP.gptr.size())) != hipSuccess) return e;
+        } else if (!LP.dense) {
             if (l + 1 >= nx) return hipErrorInvalidValue;  // a hierarchy must end on a dense level
             AmgLevel& L = H.lv[l + 1];
             L.n = LP.Ac.n_rows; L.n_cols = LP.Ac.n_cols; L.nslice = LP.Ac.nslice; L.slots = LP.Ac.slots;

@@ -300,6 +300,7 @@ struct AmgXfer {  // level l -> l+1
     int32_t *agg = nullptr, *members = nullptr, *gptr = nullptr, *glist = nullptr;
     int32_t *members_kd = nullptr, *kd_pos = nullptr;   // fused restriction tables (RestrictArgs); null: unavailable
     bool dense = false;
+    bool onto_global = false;   // lands on my rows of the replicated global level (AmgHierarchy::rep)
     // A*P of the fine level (optional): thinner operator for the first smoothing sweep after the prolongation
     bool with_ap = false;
     int32_t ap_nslice = 0;
@@ -346,13 +347,32 @@ struct AmgHierarchy {
     // 253 | 43.0; four with (c1, c2) twice 238 | 43.3; Chebyshev on [0.37, 0.77] 242 | 44, [0.25, 0.8] 230 | 39.4,
     // [0.2, 0.8] 223 | 41.5, [0.25, 0.9] 225 | 41.7; [0.15, 0.8] and [0.25, 0.7] diverge at 10M rows (SHK_AMG_COARSE4=0)
     bool coarse4 = true;
+    bool top_four = false;       // the top level is itself a coarse level of a larger cycle (replicated hierarchy)
     double c4[4] = {1.143, 3.640, 1.430, 2.219};
     int64_t ap_nnz0 = 0;             // stored entries of the finest level's A*P operator
     int32_t n_glob = 0, offset = 0;  // dense coarsest operator: n_glob x n_glob, my rows start at `offset`
     float *x0 = nullptr, *x1 = nullptr, *cr = nullptr, *cx = nullptr;   // x1: power-iteration scratch (finest level)
     double *cdense = nullptr, *cinv = nullptr, *cglob = nullptr;   // the coarsest solve stays in double
     double* gj = nullptr;        // 2 * 1024 doubles of Gauss-Jordan scratch
+    // Replicated coarse part of a decomposed hierarchy: from the first level whose GLOBAL size is small enough, the
+    // level is gathered (one all-reduce of the right-hand side per cycle) and the rest of the cycle runs on every
+    // GPU redundantly, as the single-GPU hierarchy `rep` whose top operator is that global level -- no ghost
+    // exchange below it, and no loss of couplings.  The arrays below belong to the distributed hierarchy ...
+    AmgHierarchy* rep = nullptr;
+    int32_t rep_row0 = 0, rep_n = 0;          // my rows [rep_row0, rep_row0 + n) of the rep_n global rows
+    float *rep_rloc = nullptr, *rep_xglob = nullptr;
+    double *rep_rglob = nullptr, *rep_gtmp = nullptr;   // gathered right-hand side; gathered operator values
+    // ... and these to `rep` itself: its own top operator (global level), values refreshed by the owner hierarchy
+    int32_t *t_ptr = nullptr, *t_col = nullptr, *t_cbase = nullptr, *t_ptr16 = nullptr, *t_diag = nullptr;
+    uint16_t* t_col16 = nullptr;
+    uint8_t* t_rowlen = nullptr;
+    float *t_vals = nullptr, *t_dinv = nullptr;
+    int64_t t_slots = 0;
     bool ready() const { return !xf.empty(); }
+    AmgHierarchy() = default;
+    AmgHierarchy(const AmgHierarchy&) = delete;
+    AmgHierarchy& operator=(const AmgHierarchy&) = delete;
+    ~AmgHierarchy() { delete rep; }
 };
 
 // Ghost-exchange plan of one level of a subdomain (level 0 = the mesh, l >= 1 = multigrid levels).
@@ -488,10 +508,12 @@ hipError_t halo_exchange_plan(Ctx* c, const HaloPlan& P, double* vec);
 hipError_t halo_exchange_plan_f32(Ctx* c, const HaloPlan& P, float* vec);
 hipError_t allreduce_buffer(Ctx* c, const double* src, double* dst, size_t n);  // element-wise sum over subdomains
 int amg_setup_distributed(Ctx* c, std::string& err);  // collective
-hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense);
+hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense, bool decided = false);
 hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout);
 // upload one host hierarchy (shk_api.hip: owns the allocation helpers)
-hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H, int64_t n_loc0);
+hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H, int64_t n_loc0,
+                      const std::vector<int32_t>* krank0 = nullptr);   // krank0: k-d ranks of the top rows (default: the mesh's)
+hipError_t amg_upload_rep_top(Ctx* c, AmgHierarchy& R, const SellPattern& G, const std::vector<int32_t>& diag_slot);
 hipError_t allreduce_parts(Ctx* c, int first, int nslots);
 
 struct PhaseTimer {  // RAII hipEvent pair when profiling is on

@@ -527,35 +527,169 @@ static std::string coarsen_sorted(const SellPattern& Af, const std::vector<int32
     return err;
 }
 
-// Block-local hierarchy of the owned diagonal block (ghost columns dropped): needs no communication.
-std::string build_amg(HostPlan& P, const PlanOptions& opt) {
-    P.amg.clear();
-    P.amg.reserve(40);  // `Af` below points into this vector: no reallocation (4^40 rows is out of reach)
+// Block-local hierarchy on the square part of a SELL operator (columns >= n_rows dropped): needs no communication.
+std::string build_amg_levels(const SellPattern& A0, const std::vector<int32_t>& krank, const PlanOptions& opt,
+                             std::vector<AmgLevelPlan>& out) {
+    out.clear();
+    out.reserve(40);  // `Af` below points into this vector: no reallocation (4^40 rows is out of reach)
+    const int32_t n0 = A0.n_rows;
+    if ((int32_t)krank.size() != n0) return "amg: k-d ranks do not match the operator";
     // dense coarsest level: as large as its O(n^3) inversion stays small next to the fine-level work
     // (n^3 <= 250 nnz: 2441 rows at 10M vertices, 977 at 1M), and never so large that a small mesh gets no
     // hierarchy at all.  Measured at 10M rows: 38 -> 153 -> 610 dense rows = 254 -> 218 -> 165 iterations.
-    const int by_cost = (int)std::cbrt(250.0 * (double)P.A.nnz);
+    const int by_cost = (int)std::cbrt(250.0 * (opt.amg_cost_nnz > 0 ? opt.amg_cost_nnz : (double)A0.nnz));
     const int coarsest = std::min(std::min(std::min(4096, std::max(4, opt.amg_coarsest)), std::max(64, by_cost)),
-                                  (int)std::max<int64_t>(64, P.n_own / 16));
-    const SellPattern* Af = &P.A;
-    std::vector<int32_t> agg(P.n_own), colmap;
-    for (int64_t i = 0; i < P.n_own; ++i) agg[i] = P.krank[i] / 4;
+                                  (int)std::max<int64_t>(64, n0 / 16));
+    const SellPattern* Af = &A0;
+    std::vector<int32_t> agg(n0), colmap;
+    for (int32_t i = 0; i < n0; ++i) agg[i] = krank[i] / 4;
     while (Af->n_rows > coarsest) {
         const int32_t nc = (Af->n_rows + 3) / 4;
-        P.amg.emplace_back();
+        out.emplace_back();
         colmap.assign(Af->n_cols, -1);
         std::copy(agg.begin(), agg.end(), colmap.begin());
         const bool dense = nc <= coarsest;
-        P.amg.back().with_ap = Af->n_rows > 4096;  // levels handled by launches (the one-workgroup tail prolongates)
+        out.back().with_ap = Af->n_rows > 4096;  // levels handled by launches (the one-workgroup tail prolongates)
         std::vector<int32_t> kr;
-        std::string err = dense ? coarsen(*Af, agg, colmap, nc, nc, true, P.amg.back())
-                                : coarsen_sorted(*Af, agg, colmap, nc, P.amg.back(), kr);
-        if (!err.empty()) { P.amg.clear(); return "amg: " + err; }
+        std::string err = dense ? coarsen(*Af, agg, colmap, nc, nc, true, out.back())
+                                : coarsen_sorted(*Af, agg, colmap, nc, out.back(), kr);
+        if (!err.empty()) { out.clear(); return "amg: " + err; }
         if (dense) break;
-        Af = &P.amg.back().Ac;
+        Af = &out.back().Ac;
         agg.resize(nc);
         for (int32_t I = 0; I < nc; ++I) agg[I] = kr[I] / 4;
     }
+    return std::string();
+}
+
+std::string build_amg(HostPlan& P, const PlanOptions& opt) {
+    return build_amg_levels(P.A, P.krank, opt, P.amg);
+}
+
+static std::string aggregate_members(const std::vector<int32_t>& agg, int32_t n_coarse, std::vector<int32_t>& members) {
+    members.assign((size_t)4 * n_coarse, -1);
+    std::vector<uint8_t> cnt(n_coarse, 0);
+    for (int32_t i = 0; i < (int32_t)agg.size(); ++i) {
+        const int32_t I = agg[i];
+        if (I < 0 || I >= n_coarse) return "aggregate id out of range";
+        if (cnt[I] >= 4) return "aggregate with more than 4 members";
+        members[(size_t)4 * I + cnt[I]++] = i;
+    }
+    for (int32_t I = 0; I < n_coarse; ++I) {
+        if (cnt[I] == 0) return "empty aggregate";
+        const int32_t g0 = members[(size_t)4 * I] / 256;
+        for (int m = 1; m < cnt[I]; ++m)
+            if (members[(size_t)4 * I + m] / 256 != g0) return "aggregate straddles a 256-row group";
+    }
+    return std::string();
+}
+
+std::string coarse_rows(const SellPattern& Af, const std::vector<int32_t>& agg, const std::vector<int32_t>& colmap,
+                        int32_t n_coarse, int32_t diag0, std::vector<int32_t>& rp, std::vector<int32_t>& ci) {
+    if ((int32_t)agg.size() != Af.n_rows || (int32_t)colmap.size() != Af.n_cols) return "coarse_rows: map sizes";
+    std::vector<int32_t> members, tmp;
+    std::string err = aggregate_members(agg, n_coarse, members);
+    if (!err.empty()) return err;
+    rp.assign(n_coarse + 1, 0);
+    ci.clear();
+    for (int32_t I = 0; I < n_coarse; ++I) {
+        tmp.clear();
+        for (int m = 0; m < 4; ++m) {
+            const int32_t i = members[(size_t)4 * I + m];
+            if (i < 0) continue;
+            const int32_t s = i / kSlice, l = i % kSlice, base = Af.ptr[s];
+            for (int k = 0; k < Af.rowlen[i]; ++k) {
+                const int32_t J = colmap[Af.col[base + k * kSlice + l]];
+                if (J >= 0) tmp.push_back(J);
+            }
+        }
+        std::sort(tmp.begin(), tmp.end());
+        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+        auto it = std::lower_bound(tmp.begin(), tmp.end(), diag0 + I);
+        if (it == tmp.end() || *it != diag0 + I) return "coarse row without a diagonal";
+        std::rotate(tmp.begin(), it, it + 1);
+        if (tmp.size() > 255) return "coarse row longer than 255";
+        ci.insert(ci.end(), tmp.begin(), tmp.end());
+        rp[I + 1] = (int32_t)ci.size();
+    }
+    return std::string();
+}
+
+std::string sell_from_csr(int32_t n_rows, int32_t n_cols, const std::vector<int32_t>& rp,
+                          const std::vector<int32_t>& ci, SellPattern& C, std::vector<int32_t>& diag_slot) {
+    if ((int32_t)rp.size() != n_rows + 1 || rp[n_rows] != (int32_t)ci.size()) return "sell_from_csr: bad row pointers";
+    C = SellPattern();
+    C.n_rows = n_rows;
+    C.n_cols = n_cols;
+    C.nslice = (n_rows + kSlice - 1) / kSlice;
+    C.rowlen.assign((size_t)C.nslice * kSlice, 0);
+    C.ptr.assign(C.nslice + 1, 0);
+    C.nnz = rp[n_rows];
+    for (int32_t I = 0; I < n_rows; ++I) {
+        const int len = rp[I + 1] - rp[I];
+        if (len < 1 || len > 255) return "sell_from_csr: row length out of range";
+        if (ci[rp[I]] != I) return "sell_from_csr: the diagonal must come first";
+        C.rowlen[I] = (uint8_t)len;
+        C.max_row_len = std::max(C.max_row_len, len);
+    }
+    int64_t slots = 0;
+    for (int32_t s = 0; s < C.nslice; ++s) {
+        int w = 0;
+        for (int l = 0; l < kSlice; ++l) w = std::max(w, (int)C.rowlen[(size_t)s * kSlice + l]);
+        slots += (int64_t)w * kSlice;
+        if (slots > INT32_MAX) return "sell_from_csr: too many slots";
+        C.ptr[s + 1] = (int32_t)slots;
+    }
+    C.slots = slots;
+    C.col.assign(slots, 0);
+    diag_slot.resize(n_rows);
+    for (int32_t I = 0; I < n_rows; ++I) {
+        const int32_t s = I / kSlice, l = I % kSlice, base = C.ptr[s];
+        const int w = (C.ptr[s + 1] - base) / kSlice;
+        for (int k = 0; k < w; ++k) C.col[base + k * kSlice + l] = (k < C.rowlen[I]) ? ci[rp[I] + k] : I;
+        diag_slot[I] = base + l;
+    }
+    C.build_col16();
+    return std::string();
+}
+
+std::string coarsen_onto_global(const SellPattern& Af, const std::vector<int32_t>& agg,
+                                const std::vector<int32_t>& colmap, int32_t n_coarse, int32_t row0,
+                                const SellPattern& G, AmgLevelPlan& L) {
+    const int32_t nf = Af.n_rows;
+    if ((int32_t)agg.size() != nf || (int32_t)colmap.size() != Af.n_cols) return "coarsen_onto_global: map sizes";
+    if (row0 < 0 || row0 + n_coarse > G.n_rows) return "coarsen_onto_global: rows outside the global level";
+    L.n_fine = nf;
+    L.n_coarse = n_coarse;
+    L.n_coarse_cols = G.n_rows;
+    L.agg = agg;
+    L.dense = false;
+    L.onto_global = true;
+    std::string err = aggregate_members(agg, n_coarse, L.members);
+    if (!err.empty()) return err;
+    std::vector<int32_t> target((size_t)Af.slots, -1);
+    for (int32_t i = 0; i < nf; ++i) {
+        const int32_t s = i / kSlice, l = i % kSlice, base = Af.ptr[s], I = row0 + agg[i];
+        const int32_t gs = I / kSlice, gl = I % kSlice, gbase = G.ptr[gs];
+        const int len = G.rowlen[I];
+        for (int k = 0; k < Af.rowlen[i]; ++k) {
+            const int32_t slot = base + k * kSlice + l;
+            const int32_t J = colmap[Af.col[slot]];
+            if (J < 0) continue;
+            int kk = 0;
+            while (kk < len && G.col[gbase + kk * kSlice + gl] != J) ++kk;
+            if (kk == len) return "coarsen_onto_global: entry missing from the global pattern";
+            target[slot] = gbase + kk * kSlice + gl;
+        }
+    }
+    L.gptr.assign(G.slots + 1, 0);
+    for (int64_t s = 0; s < Af.slots; ++s)
+        if (target[s] >= 0) L.gptr[target[s] + 1]++;
+    for (int64_t s = 0; s < G.slots; ++s) L.gptr[s + 1] += L.gptr[s];
+    L.glist.resize(L.gptr[G.slots]);
+    std::vector<int32_t> fill(L.gptr.begin(), L.gptr.end() - 1);
+    for (int64_t s = 0; s < Af.slots; ++s)
+        if (target[s] >= 0) L.glist[fill[target[s]]++] = (int32_t)s;
     return std::string();
 }
 

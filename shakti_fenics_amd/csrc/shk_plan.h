@@ -25,6 +25,8 @@ struct PlanOptions {
     bool reorder = true;   // internal k-d order + window sort (false: keep the caller's numbering)
     bool amg = true;       // also build the aggregation-multigrid hierarchy (of the owned diagonal block)
     int amg_coarsest = 4096; // cap of the dense coarsest level of a local hierarchy (inverted by Gauss-Jordan)
+    double amg_cost_nnz = 0; // entries of the finest operator that the dense level's size is weighed against
+                             // (0: those of the operator the hierarchy is built on)
 };
 
 // SELL-64 sparsity of the owned rows; columns index owned + ghost vertices.
@@ -57,6 +59,8 @@ struct AmgLevelPlan {
     std::vector<int32_t> diag_slot; // n_coarse        : slot of the coarse diagonal (sparse levels)
     std::vector<int32_t> kd_pos;    // n_coarse : coarse row (storage position) of k-d rank k; empty = identity
     bool dense = false;
+    bool onto_global = false;       // the coarse level is a GLOBAL sparse level replicated on every subdomain: gptr /
+                                    // glist target its slots, n_coarse = my rows of it, n_coarse_cols = all of its rows
     // A*P (fine rows x coarse columns, ~4 entries per row instead of ~7): lets the first smoothing sweep after
     // the prolongation read a thinner operator and skip the prolongated vector altogether:
     //   x1 = alpha P e + w D^-1 (r - alpha (A P) e)
@@ -96,6 +100,22 @@ std::string build_plan(int64_t n_own, int64_t n_loc, int64_t ne, const double* x
 std::string build_amg(HostPlan& P, const PlanOptions& opt);
 std::string coarsen(const SellPattern& Af, const std::vector<int32_t>& agg, const std::vector<int32_t>& colmap,
                     int32_t n_coarse, int32_t n_coarse_cols, bool dense, AmgLevelPlan& L);
+
+// Replicated coarse levels of a decomposed hierarchy (shk_amg.hip: amg_setup_distributed).
+//   coarse_rows          the rows of the coarse operator that `agg` / `colmap` (global column ids) produce from Af:
+//                        CSR, sorted unique columns, the diagonal (column diag0 + I) first
+//   sell_from_csr        SELL-64 pattern of such rows (all subdomains' rows concatenated = the global level)
+//   coarsen_onto_global  the transfer plan of a subdomain's level onto rows [row0, row0 + n_coarse) of G
+//   build_amg_levels     a block-local hierarchy (like build_amg) on any SELL operator; krank = k-d rank of its rows
+std::string coarse_rows(const SellPattern& Af, const std::vector<int32_t>& agg, const std::vector<int32_t>& colmap,
+                        int32_t n_coarse, int32_t diag0, std::vector<int32_t>& rp, std::vector<int32_t>& ci);
+std::string sell_from_csr(int32_t n_rows, int32_t n_cols, const std::vector<int32_t>& rp,
+                          const std::vector<int32_t>& ci, SellPattern& C, std::vector<int32_t>& diag_slot);
+std::string coarsen_onto_global(const SellPattern& Af, const std::vector<int32_t>& agg,
+                                const std::vector<int32_t>& colmap, int32_t n_coarse, int32_t row0,
+                                const SellPattern& G, AmgLevelPlan& L);
+std::string build_amg_levels(const SellPattern& A0, const std::vector<int32_t>& krank, const PlanOptions& opt,
+                             std::vector<AmgLevelPlan>& out);
 
 // External CSR (rows = external owned ids, columns external local ids ascending) of a SELL pattern.
 void sell_to_csr(const HostPlan& P, const double* sell_vals, std::vector<int32_t>& rowptr,

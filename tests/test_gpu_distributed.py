@@ -16,8 +16,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launch(nproc, transport, port, extra=()):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _launch(nproc, transport, port, extra=(), env_extra=None):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"),
            "--transport", transport, *extra]
@@ -38,6 +38,19 @@ def test_partitioned_matches_single_at_1m_dof():
     undecomposed run's to 1e-7, same Newton iteration counts, Krylov counts within the distributed hierarchy's
     margin, ghost copies identical to their owners."""
     r = _launch(2, "gloo", 29561, ("--precond", "amg", "--nx", "2236", "--ny", "447", "--lx", "100e3", "--ly", "20e3"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    rep = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert rep["ok"] and rep["ghost_mismatch"] == 0.0 and max(rep["errs"].values()) < 1e-7
+
+
+@pytest.mark.parametrize("rep_rows", ["30000", "8000"])
+def test_replicated_coarse_levels_four_subdomains(rep_rows):
+    """The gathered-and-replicated coarse part of the distributed multigrid on an 80k-DOF mesh
+    split four ways, taking over at level 1 (20k global rows) and at level 2 (5k): same fields as the undecomposed run,
+    same Newton counts, Krylov counts at the one-subdomain level.  (Four subdomains make the replicated level larger
+    than a subdomain's own share of it, the case that needs the reduction partials cleared.)"""
+    r = _launch(4, "gloo", 29565 + int(rep_rows) // 8000, ("--precond", "amg", "--nx", "400", "--ny", "200"),
+                {"SHK_AMG_REP_ROWS": rep_rows})
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     rep = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert rep["ok"] and rep["ghost_mismatch"] == 0.0 and max(rep["errs"].values()) < 1e-7
