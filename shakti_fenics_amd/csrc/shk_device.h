@@ -330,12 +330,11 @@ struct AmgHierarchy {
     bool dense_valid = false;    // the dense coarsest inverse has been built at least once
     int dense_age = 0, dense_period = 8;   // Newton solves since / between rebuilds of a big inverse (SHK_AMG_DENSE_PERIOD)
     int its_fresh = 0, its_last = 0;       // Krylov iterations of the first solve after a rebuild / of the last solve
-    int halo_levels = 99;        // levels [0, halo_levels) exchange ghosts inside the smoother (SHK_AMG_HALO_LEVELS):
-                                 // all of them by default.  Rehearsed with 4 subdomains on one GPU, BiCGStab
-                                 // iterations per Newton iteration for 1 / 2 / 3 / 4 / all levels exchanging:
-                                 // 10M rows 118 / 76 / 67 / 61 / 48 (one subdomain: 45), 1M rows 70 / 54 / 49 / - / 38
-                                 // (40).  Each level costs two message rounds per cycle; 76 -> 48 iterations pays
-                                 // for 14 -> ~28 rounds per iteration unless a round costs more than ~60 us.
+    int halo_levels = 99;        // decomposed levels [0, halo_levels) exchange ghosts inside the smoother
+                                 // (SHK_AMG_HALO_LEVELS): all of them by default -- below the decomposed levels
+                                 // sits the replicated coarse part (`rep`), which needs no exchange.  Block-local
+                                 // smoothing instead is expensive: 4 subdomains at 10M rows, 1 / 2 / 3 / 4 / all
+                                 // levels exchanging = 118 / 76 / 67 / 61 / 48 iterations (one subdomain: 45).
     // Two damped-Jacobi sweeps x <- x + (c_k / lambda) D^-1 (r - A x), lambda ~ the largest eigenvalue of D^-1 A
     // over the levels (power iteration at the rebuilds of the dense inverse, +10 % because it converges from
     // below).  c = (2.35, 1.41) is the pair measured best on the 10M-row system (lambda there = 2.35: w = 1.0,
