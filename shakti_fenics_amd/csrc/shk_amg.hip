@@ -192,8 +192,10 @@ struct AmgFirstArgs {
     const float* vals;       // A*P values
     const float* dinv;
     const TR* r;
-    const float* e;          // coarse correction
+    const float* e;          // coarse correction, indexed by the A*P columns
     const int32_t* agg;
+    int32_t agg_off;         // e[agg_off + agg[row]] is the row's own aggregate (agg holds a subdomain's local ids; the
+                             // columns of a transfer onto the replicated global level are global)
     float* xo;
     float omega, alpha;
     const int* done;
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(kBlock) void k_amg_first(const AmgFirstArgs<TR> a) 
         const float rr = (float)a.r[row];
         const float di = a.dinv[row];
         const float sum = sell_row_sum(a.AP, it.m, a.vals, a.e, lane);
-        if (it.s * kSlice + lane < a.AP.n_rows) a.xo[row] = a.alpha * a.e[ag] + a.omega * di * (rr - a.alpha * sum);
+        if (it.s * kSlice + lane < a.AP.n_rows) a.xo[row] = a.alpha * a.e[a.agg_off + ag] + a.omega * di * (rr - a.alpha * sum);
     }
 }
 
@@ -652,9 +654,17 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
     for (size_t l = lt; l-- > 0;) {
         const AmgXfer& X = H.xf[l];
         const float* ec = X.dense ? H.cx : X.onto_global ? H.rep_xglob + H.rep_row0 : H.lv[l + 1].x2;
-        const bool fused = X.with_ap && !H.distributed;
         const bool halo = H.distributed && (int)l < H.halo_levels;
         const HaloPlan* HP = halo ? &c->comm.plans[H.plan_of[l]] : nullptr;
+        // first sweep on A*P: its columns are the coarser level's columns, so a decomposed coarser level must
+        // exchange its result first (a smaller message than exchanging the prolongated vector); the replicated
+        // level's result is complete on every subdomain
+        const bool fused = X.with_ap && !X.dense && (!H.distributed || X.onto_global || (int)(l + 1) < H.halo_levels);
+        const float* e_cols = X.onto_global ? H.rep_xglob : ec;
+        const int32_t agg_off = X.onto_global ? H.rep_row0 : 0;
+        if (fused && H.distributed && !X.onto_global &&
+            (e = halo_exchange_plan_f32(c, c->comm.plans[H.plan_of[l + 1]], H.lv[l + 1].x2)) != hipSuccess)
+            return e;
         const DevSell A = level_sell(c, H, l);
         const dim3 g(std::min((A.nslice + 3) / 4, 2048));
         if (l == 0) {
@@ -667,7 +677,7 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
             if (fused) {
                 AmgFirstArgs<double> f{DevSell{X.n_fine, X.n_coarse_cols, X.ap_nslice, sell_fits_cache(X.ap_slots, kAmgSlotBytes),
                                                X.ap_ptr, X.ap_col, X.ap_rowlen, X.ap_cbase, X.ap_ptr16, X.ap_col16},
-                                       X.ap_vals, H.top_dinv, rin, ec, X.agg, H.x0, omega, alpha, done};
+                                       X.ap_vals, H.top_dinv, rin, e_cols, X.agg, agg_off, H.x0, omega, alpha, done};
                 launch_phase(c, SHK_PH_AMG_FIRST, k_amg_first<true, double>, g, dim3(kBlock), 0, f);
             } else {
                 {
@@ -697,7 +707,7 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
             if (fused) {
                 AmgFirstArgs<float> f{DevSell{X.n_fine, X.n_coarse_cols, X.ap_nslice, sell_fits_cache(X.ap_slots, kAmgSlotBytes),
                                               X.ap_ptr, X.ap_col, X.ap_rowlen, X.ap_cbase, X.ap_ptr16, X.ap_col16},
-                                      X.ap_vals, L.dinv, L.r, ec, X.agg, L.x, lw1, alpha, done};
+                                      X.ap_vals, L.dinv, L.r, e_cols, X.agg, agg_off, L.x, lw1, alpha, done};
                 PhaseTimer t(c, SHK_PH_AMG_COARSE);
                 hipLaunchKernelGGL((k_amg_first<false, float>), g, dim3(kBlock), 0, c->stream, f);
             } else {
@@ -713,6 +723,15 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
                 launch_post<false>(c, A, L.vals, L.dinv, (const float*)L.r, (const float*)L.x2, L.x, lw1, done);
             }
             if (halo && (e = halo_exchange_plan_f32(c, *HP, L.x)) != hipSuccess) return e;
+            if (halo && fused && more) {
+                // The third sweep reads x2, whose ghost segment no exchange of THIS cycle has filled when the first
+                // sweep ran on A*P (it would hold the previous cycle's values: the preconditioner would stop being a
+                // function of its input, and BiCGStab breaks down).  Give it the ghosts just received for x.
+                const int64_t ng = HP->recv_ptr.back();
+                if (ng > 0 && (e = hipMemcpyAsync(L.x2 + HP->n_own, L.x + HP->n_own, (size_t)ng * sizeof(float),
+                                                  hipMemcpyDeviceToDevice, c->stream)) != hipSuccess)
+                    return e;
+            }
             PhaseTimer t(c, SHK_PH_AMG_COARSE);
             launch_post<false>(c, A, L.vals, L.dinv, (const float*)L.r, (const float*)L.x, L.x2, lw2, done);
             if (more) {
@@ -867,6 +886,9 @@ int amg_setup_distributed(Ctx* c, std::string& err) {
             CP.send_ptr.push_back((int64_t)CP.h_send_idx.size());
         }
         plans.emplace_back();
+        // first sweep on the A*P operator (like the single-GPU hierarchy), except towards a shared dense level, whose
+        // solve leaves only this subdomain's rows of the correction behind
+        plans.back().with_ap = !next_dense && Af->n_rows > 4096;
         const int32_t ncols = glob_cols ? offs[R] : (int32_t)(nc_own + cghost);
         std::string perr;
         if (next_rep) {

@@ -301,6 +301,74 @@ std::string build_plan(int64_t n_own, int64_t n_loc, int64_t ne, const double* x
     return std::string();
 }
 
+// A*P of one transfer: pattern (fine rows x coarse columns colmap[.]) and the gather plan of its values.
+static void build_ap_plan(const SellPattern& Af, const std::vector<int32_t>& colmap, int32_t n_coarse_cols,
+                          AmgLevelPlan& L) {
+    const int32_t nf = Af.n_rows;
+    // A*P pattern: per fine row the sorted unique coarse columns of its entries (own aggregate first)
+    SellPattern& Q = L.AP;
+    Q.n_rows = nf;
+    Q.n_cols = n_coarse_cols;
+    Q.nslice = Af.nslice;
+    Q.rowlen.assign((size_t)Q.nslice * kSlice, 0);
+    Q.ptr.assign(Q.nslice + 1, 0);
+    std::vector<int32_t> rp2(nf + 1, 0), ci2, tmp2;
+    ci2.reserve((size_t)Af.nnz * 2 / 3);
+    for (int32_t i = 0; i < nf; ++i) {
+        const int32_t s = i / kSlice, l = i % kSlice, base = Af.ptr[s];
+        tmp2.clear();
+        for (int k = 0; k < Af.rowlen[i]; ++k) {
+            const int32_t J = colmap[Af.col[base + k * kSlice + l]];
+            if (J >= 0) tmp2.push_back(J);
+        }
+        std::sort(tmp2.begin(), tmp2.end());
+        tmp2.erase(std::unique(tmp2.begin(), tmp2.end()), tmp2.end());
+        Q.rowlen[i] = (uint8_t)tmp2.size();
+        Q.max_row_len = std::max(Q.max_row_len, (int)tmp2.size());
+        ci2.insert(ci2.end(), tmp2.begin(), tmp2.end());
+        rp2[i + 1] = (int32_t)ci2.size();
+    }
+    Q.nnz = rp2[nf];
+    int64_t qs = 0;
+    for (int32_t s = 0; s < Q.nslice; ++s) {
+        int w = 0;
+        for (int l = 0; l < kSlice; ++l) w = std::max(w, (int)Q.rowlen[(size_t)s * kSlice + l]);
+        qs += (int64_t)w * kSlice;
+        Q.ptr[s + 1] = (int32_t)qs;
+    }
+    Q.slots = qs;
+    Q.col.assign(qs, 0);
+    std::vector<int32_t> target2((size_t)Af.slots, -1);
+    for (int32_t i = 0; i < nf; ++i) {
+        const int32_t s = i / kSlice, l = i % kSlice, base = Af.ptr[s], qb = Q.ptr[s];
+        const int w = (Q.ptr[s + 1] - qb) / kSlice;
+        const int32_t* row = ci2.data() + rp2[i];
+        const int len = rp2[i + 1] - rp2[i];
+        for (int k = 0; k < w; ++k) Q.col[qb + k * kSlice + l] = (k < len) ? row[k] : row[0];  // padding: any valid column
+        for (int k = 0; k < Af.rowlen[i]; ++k) {
+            const int32_t slot = base + k * kSlice + l;
+            const int32_t J = colmap[Af.col[slot]];
+            if (J < 0) continue;
+            const int kk = (int)(std::lower_bound(row, row + len, J) - row);
+            target2[slot] = qb + kk * kSlice + l;
+        }
+    }
+    for (int32_t i = nf; i < Q.nslice * kSlice; ++i) {  // tail padding rows
+        const int32_t s = i / kSlice, l = i % kSlice, qb = Q.ptr[s];
+        const int w = (Q.ptr[s + 1] - qb) / kSlice;
+        for (int k = 0; k < w; ++k) Q.col[qb + k * kSlice + l] = 0;
+    }
+    Q.build_col16();
+    L.ap_gptr.assign(qs + 1, 0);
+    for (int64_t s = 0; s < Af.slots; ++s)
+        if (target2[s] >= 0) L.ap_gptr[target2[s] + 1]++;
+    for (int64_t s = 0; s < qs; ++s) L.ap_gptr[s + 1] += L.ap_gptr[s];
+    L.ap_glist.resize(L.ap_gptr[qs]);
+    std::vector<int32_t> fill2(L.ap_gptr.begin(), L.ap_gptr.end() - 1);
+    for (int64_t s = 0; s < Af.slots; ++s)
+        if (target2[s] >= 0) L.ap_glist[fill2[target2[s]]++] = (int32_t)s;
+}
+
 // ---- aggregation multigrid hierarchy (static patterns) ----
 // One coarsening step.  `agg` maps the fine rows to coarse rows; `colmap` maps EVERY fine column (owned
 // and ghost) to a coarse column, or -1 to drop it (ghost couplings of a block-local hierarchy).  Sparse result:
@@ -412,70 +480,7 @@ std::string coarsen(const SellPattern& Af, const std::vector<int32_t>& agg, cons
             }
         }
     }
-    if (L.with_ap) {
-        // A*P pattern: per fine row the sorted unique coarse columns of its entries (own aggregate first)
-        SellPattern& Q = L.AP;
-        Q.n_rows = nf;
-        Q.n_cols = n_coarse_cols;
-        Q.nslice = Af.nslice;
-        Q.rowlen.assign((size_t)Q.nslice * kSlice, 0);
-        Q.ptr.assign(Q.nslice + 1, 0);
-        std::vector<int32_t> rp2(nf + 1, 0), ci2, tmp2;
-        ci2.reserve((size_t)Af.nnz * 2 / 3);
-        for (int32_t i = 0; i < nf; ++i) {
-            const int32_t s = i / kSlice, l = i % kSlice, base = Af.ptr[s];
-            tmp2.clear();
-            for (int k = 0; k < Af.rowlen[i]; ++k) {
-                const int32_t J = colmap[Af.col[base + k * kSlice + l]];
-                if (J >= 0) tmp2.push_back(J);
-            }
-            std::sort(tmp2.begin(), tmp2.end());
-            tmp2.erase(std::unique(tmp2.begin(), tmp2.end()), tmp2.end());
-            Q.rowlen[i] = (uint8_t)tmp2.size();
-            Q.max_row_len = std::max(Q.max_row_len, (int)tmp2.size());
-            ci2.insert(ci2.end(), tmp2.begin(), tmp2.end());
-            rp2[i + 1] = (int32_t)ci2.size();
-        }
-        Q.nnz = rp2[nf];
-        int64_t qs = 0;
-        for (int32_t s = 0; s < Q.nslice; ++s) {
-            int w = 0;
-            for (int l = 0; l < kSlice; ++l) w = std::max(w, (int)Q.rowlen[(size_t)s * kSlice + l]);
-            qs += (int64_t)w * kSlice;
-            Q.ptr[s + 1] = (int32_t)qs;
-        }
-        Q.slots = qs;
-        Q.col.assign(qs, 0);
-        std::vector<int32_t> target2((size_t)Af.slots, -1);
-        for (int32_t i = 0; i < nf; ++i) {
-            const int32_t s = i / kSlice, l = i % kSlice, base = Af.ptr[s], qb = Q.ptr[s];
-            const int w = (Q.ptr[s + 1] - qb) / kSlice;
-            const int32_t* row = ci2.data() + rp2[i];
-            const int len = rp2[i + 1] - rp2[i];
-            for (int k = 0; k < w; ++k) Q.col[qb + k * kSlice + l] = (k < len) ? row[k] : row[0];  // padding: any valid column
-            for (int k = 0; k < Af.rowlen[i]; ++k) {
-                const int32_t slot = base + k * kSlice + l;
-                const int32_t J = colmap[Af.col[slot]];
-                if (J < 0) continue;
-                const int kk = (int)(std::lower_bound(row, row + len, J) - row);
-                target2[slot] = qb + kk * kSlice + l;
-            }
-        }
-        for (int32_t i = nf; i < Q.nslice * kSlice; ++i) {  // tail padding rows
-            const int32_t s = i / kSlice, l = i % kSlice, qb = Q.ptr[s];
-            const int w = (Q.ptr[s + 1] - qb) / kSlice;
-            for (int k = 0; k < w; ++k) Q.col[qb + k * kSlice + l] = 0;
-        }
-        Q.build_col16();
-        L.ap_gptr.assign(qs + 1, 0);
-        for (int64_t s = 0; s < Af.slots; ++s)
-            if (target2[s] >= 0) L.ap_gptr[target2[s] + 1]++;
-        for (int64_t s = 0; s < qs; ++s) L.ap_gptr[s + 1] += L.ap_gptr[s];
-        L.ap_glist.resize(L.ap_gptr[qs]);
-        std::vector<int32_t> fill2(L.ap_gptr.begin(), L.ap_gptr.end() - 1);
-        for (int64_t s = 0; s < Af.slots; ++s)
-            if (target2[s] >= 0) L.ap_glist[fill2[target2[s]]++] = (int32_t)s;
-    }
+    if (L.with_ap) build_ap_plan(Af, colmap, n_coarse_cols, L);
     // invert: coarse slot -> ascending list of fine slots
     L.gptr.assign(nslots_c + 1, 0);
     for (int64_t s = 0; s < Af.slots; ++s)
@@ -690,6 +695,7 @@ std::string coarsen_onto_global(const SellPattern& Af, const std::vector<int32_t
     std::vector<int32_t> fill(L.gptr.begin(), L.gptr.end() - 1);
     for (int64_t s = 0; s < Af.slots; ++s)
         if (target[s] >= 0) L.glist[fill[target[s]]++] = (int32_t)s;
+    if (L.with_ap) build_ap_plan(Af, colmap, G.n_rows, L);   // columns = global rows of the replicated level
     return std::string();
 }
 
