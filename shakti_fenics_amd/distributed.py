@@ -6,7 +6,11 @@ own stream (`csrc/shk_comm.hip`), or the host-staged callback transport over glo
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on these hosts (RCCL across processes)
 
 from . import _lib
 from .partition import Subdomain
