@@ -340,7 +340,10 @@ struct AmgHierarchy {
     // below).  c = (2.35, 1.41) is the pair measured best on the 10M-row system (lambda there = 2.35: w = 1.0,
     // 0.6; 61 iterations per Newton step against 69 for 0.7, 0.7 -- and 0.9, 0.9 diverges).  (SHK_AMG_W1/W2)
     double lambda = 0.0;             // 0: not estimated yet
-    double c1 = 2.35, c2 = 1.41;
+    double c1 = 2.35, c2 = 1.25;     // w = (1.03, 0.55) on the synthetic meshes.  Iterations per Newton iteration at 10M |
+                                     // 1M rows with the final cycle: (1.03, 0.62) 45.1 | 40.9, (1.03, 0.55) 44.8 | 39.8,
+                                     // (0.95, 0.55) 46.0 | 41.2, (0.85, 0.50) 48.0 | 40.9 -- and (1.03, 0.70) 97.6 | 41.9: the
+                                     // second damping sits well below that edge
     // Levels >= 1 without ghost exchanges run FOUR sweeps, dampings c4[k] / lambda = the Chebyshev roots for
     // [0.25, 0.9] lambda, small and large steps interleaved.  Measured ms/step at 10M | 1M rows: two sweeps
     // 253 | 43.0; four with (c1, c2) twice 238 | 43.3; Chebyshev on [0.37, 0.77] 242 | 44, [0.25, 0.8] 230 | 39.4,
