@@ -124,6 +124,36 @@ def test_ten_steps_match_oracle(hip, precond):
     ctx.close()
 
 
+def test_three_steps_at_62k_dof_match_oracle(hip):
+    """The largest size the LU oracle finishes in seconds (the mesh of bench.py's cpu_baseline leg, 560 x 112 on the
+    100 km x 20 km geometry, with the lake storage term and 12 moulins): a multigrid hierarchy of four levels, the
+    four-level restriction kernel and the dense level's Gauss-Jordan inverse are all on this path."""
+    from shakti_fenics_amd.mesh import rectangle_mesh
+    from shakti_fenics_amd.synthetic import N_BDRY, outflow_predicate, synthetic_fields
+    dom = rectangle_mesh(560, 112, 100e3, 20e3, order="morton")
+    sf = synthetic_fields(dom, storage_on=True, moulins=12)
+    nv = dom.num_vertices
+    f = O.Fields(N=sf["N_init"].copy(), N_n=sf["N_init"].copy(), b=np.abs(sf["b_init"]), q=sf["q_init"].copy(),
+                 melt_n=np.zeros(nv), z_b=sf["z_b"], z_s=sf["z_s"], G=sf["G"], storage=sf["lake_bdry"], inputs=sf["inputs"])
+    bc = O.boundary_dofs(dom.xy, dom.cells, outflow_predicate(dom))
+    ctx = hip.ShaktiHip(dom.xy, dom.cells)
+    ctx.set_params(precond=hip.PRECOND["amg"])
+    upload(ctx, f, bc, N_BDRY)
+    assert ctx.plan_stats()["amg_levels"] >= 4
+    ts = np.arange(4) * DT
+    fo, log = O.run(dom.xy, dom.cells, f.copy(), ts, O.Params(), bc, N_BDRY, nsteps=3)
+    its = []
+    for i in range(3):
+        info = ctx.step(0.1 * DT if i == 0 else DT)
+        assert info.converged
+        its.append(info.newton_its)
+    assert its == [l["niter"] for l in log]
+    assert rel_l2(ctx.get_field("N"), fo.N) < 1e-7          # BASELINE.json's bar on this field: 1e-6
+    assert rel_l2(ctx.get_field("b"), fo.b) < 1e-7
+    assert rel_l2(ctx.get_field("q"), fo.q) < 1e-6
+    ctx.close()
+
+
 def test_errors_are_loud(hip):
     dom, f, bc, g = make_case()
     ctx = hip.ShaktiHip(dom.xy, dom.cells)
