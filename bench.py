@@ -70,7 +70,7 @@ def cpu_baseline(args) -> dict:
     bc = O.boundary_dofs(dom.xy, dom.cells, outflow_predicate(dom))
     prm = O.Params()
     last, _ = O.last_cell_of_vertex(nv, dom.cells)
-    steps = 3
+    steps = 5   # ~12-15 s of single-thread work on the GPU box's host
     t0 = time.perf_counter()
     its = 0
     for i in range(steps):
