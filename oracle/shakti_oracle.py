@@ -79,8 +79,20 @@ def head(N, z_b, z_s, prm: Params):
 
 
 def _cell_grad(f, cells, grads):
-    """Gradient of a P1 field on each cell: (ne,2)."""
-    return np.einsum("ei,eid->ed", f[cells], grads)
+    """Gradient of a P1 coefficient on each cell: (ne,2).  FFCx evaluates the reference gradient of a
+    coefficient from the tabulated P1 derivatives (-1, 1, 0), (-1, 0, 1), i.e. as the nodal DIFFERENCES
+    f1 - f0, f2 - f0, and then applies the inverse Jacobian: rounding is relative to the differences, not
+    to the magnitude of f (this matters for the head, ~1e3 m, differenced over cells of ~10 m)."""
+    fc = f[cells]
+    return (fc[:, 1] - fc[:, 0])[:, None] * grads[:, 1, :] + (fc[:, 2] - fc[:, 0])[:, None] * grads[:, 2, :]
+
+
+def _head_grad(N, z_b, z_s, cells, grads, prm):
+    """grad(Head(N, z_b, z_s)) (`constitutive.py:6-9`): UFL pushes grad() onto the coefficients, so each of
+    z_b, z_s and N is differenced on its own and the results are combined."""
+    r = prm.rho_i / prm.rho_w
+    gzb = _cell_grad(z_b, cells, grads)
+    return gzb + r * (_cell_grad(z_s, cells, grads) - gzb) - _cell_grad(N, cells, grads) / (prm.rho_w * prm.g)
 
 
 @dataclass
@@ -112,16 +124,15 @@ def element_tensors(xy, cells, f: Fields, dt: float, prm: Params, quad=None, wan
     ne = cells.shape[0]
     rwg = prm.rho_w * prm.g
     c_m = 1.0 / prm.rho_i - 1.0 / prm.rho_w
-    h = head(f.N, f.z_b, f.z_s, prm)
-    gh = _cell_grad(h, cells, grads)  # (ne,2)
+    gh = _head_grad(f.N, f.z_b, f.z_s, cells, grads, prm)  # (ne,2)
     gb = _cell_grad(f.b, cells, grads)
     gm = _cell_grad(f.melt_n, cells, grads)
     den_b = 1.0 + np.einsum("ed,ed->e", gb, gb)
     Nc, Nnc, bc = f.N[cells], f.N_n[cells], f.b[cells]
     qxc, qyc = f.q[cells, 0], f.q[cells, 1]
     Gc, mc, sc, ic = f.G[cells], f.melt_n[cells], f.storage[cells], f.inputs[cells]
-    Fe = np.zeros((ne, 3))
-    Ke = np.zeros((ne, 3, 3)) if want_jacobian else None
+    Fe = np.zeros((ne, 3), dtype=area.dtype)   # (float64; np.longdouble inputs give an extended-precision evaluation)
+    Ke = np.zeros((ne, 3, 3), dtype=area.dtype) if want_jacobian else None
     gh_gphi = np.einsum("ed,eid->ei", gh, grads)  # grad(h).grad(phi_i)
     gphi_gphi = np.einsum("eid,ejd->eij", grads, grads)
     for xq, yq, wq in quad:
@@ -290,8 +301,7 @@ def update_explicit(xy, cells, f: Fields, dt: float, prm: Params, lastcell=None)
     tc = cells[lastcell]  # (nv,3) vertices of T*(v)
     grads, _ = p1_geometry(xy, tc)
     rwg = prm.rho_w * prm.g
-    h = head(f.N, f.z_b, f.z_s, prm)
-    gh = _cell_grad(h, tc, grads)
+    gh = _head_grad(f.N, f.z_b, f.z_s, tc, grads, prm)
     gb = _cell_grad(f.b, tc, grads)
     den_b = 1.0 + np.einsum("vd,vd->v", gb, gb)
     # R6, solvers.py:143,186

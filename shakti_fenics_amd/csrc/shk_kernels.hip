@@ -40,6 +40,11 @@ __device__ __forceinline__ double reduce_partials(const double* __restrict__ P, 
     return block_sum(a, sh4);
 }
 
+// Difference of the head between two vertices from the differences of its coefficients (constitutive.py:6-9)
+__device__ __forceinline__ double head_diff(double dzb, double dzs, double dN, const DevParams& p) {
+    return dzb + p.ri_rw * (dzs - dzb) - dN / p.rwg;
+}
+
 __device__ __forceinline__ double glen_pow(double N, const DevParams& p) {
     // |N|^(n-1), constitutive.py:31; n = 3 (params.py:10) is the square
     return p.n_is_3 ? N * N : pow(fabs(N), p.n - 1.0);
@@ -105,17 +110,20 @@ __global__ __launch_bounds__(kBlock) void k_assemble(const AsmArgs a) {
 
         const double N0 = a.N[v0], N1 = a.N[v1], N2 = a.N[v2];
         const double m0_ = a.melt_n[v0], m1_ = a.melt_n[v1], m2_ = a.melt_n[v2];
-        double h0, h1, h2;  // Head, constitutive.py:6-9
+        // grad(Head), constitutive.py:6-9.  Like FFCx, every coefficient is differenced on its own (reference
+        // gradient = nodal differences f1 - f0, f2 - f0): rounding is then relative to the differences, not to
+        // the head's magnitude (~1e3 m over cells of ~10 m), which puts the floor of ||F|| an order of magnitude
+        // lower than differencing nodal heads would.
+        double dh1, dh2;
         {
             const double zb0 = a.z_b[v0], zb1 = a.z_b[v1], zb2 = a.z_b[v2];
             const double zs0 = a.z_s[v0], zs1 = a.z_s[v1], zs2 = a.z_s[v2];
-            h0 = zb0 + p.ri_rw * (zs0 - zb0) - N0 / p.rwg;
-            h1 = zb1 + p.ri_rw * (zs1 - zb1) - N1 / p.rwg;
-            h2 = zb2 + p.ri_rw * (zs2 - zb2) - N2 / p.rwg;
+            dh1 = head_diff(zb1 - zb0, zs1 - zs0, N1 - N0, p);
+            dh2 = head_diff(zb2 - zb0, zs2 - zs0, N2 - N0, p);
         }
-        const double ghx = h0 * g0x + h1 * g1x + h2 * g2x, ghy = h0 * g0y + h1 * g1y + h2 * g2y;
-        const double gbx = b0 * g0x + b1 * g1x + b2 * g2x, gby = b0 * g0y + b1 * g1y + b2 * g2y;
-        const double gmx = m0_ * g0x + m1_ * g1x + m2_ * g2x, gmy = m0_ * g0y + m1_ * g1y + m2_ * g2y;
+        const double ghx = dh1 * g1x + dh2 * g2x, ghy = dh1 * g1y + dh2 * g2y;
+        const double gbx = (b1 - b0) * g1x + (b2 - b0) * g2x, gby = (b1 - b0) * g1y + (b2 - b0) * g2y;
+        const double gmx = (m1_ - m0_) * g1x + (m2_ - m0_) * g2x, gmy = (m1_ - m0_) * g1y + (m2_ - m0_) * g2y;
         const double gb2 = gbx * gbx + gby * gby;
         const double inv_den = 1.0 / (1.0 + gb2);
         const double gmgb = gmx * gbx + gmy * gby;
@@ -637,14 +645,14 @@ __global__ __launch_bounds__(kBlock) void k_update_a(const UpdArgs a) {
     const DevParams& p = a.p;
     for (int64_t v = blockIdx.x * (int64_t)kBlock + threadIdx.x; v < a.nv; v += (int64_t)gridDim.x * kBlock) {
         const CellGeom g = cell_geom(a.m, a.lastcell[v]);
-        const double h0 = a.z_b[g.v0] + p.ri_rw * (a.z_s[g.v0] - a.z_b[g.v0]) - a.N[g.v0] / p.rwg;
-        const double h1 = a.z_b[g.v1] + p.ri_rw * (a.z_s[g.v1] - a.z_b[g.v1]) - a.N[g.v1] / p.rwg;
-        const double h2 = a.z_b[g.v2] + p.ri_rw * (a.z_s[g.v2] - a.z_b[g.v2]) - a.N[g.v2] / p.rwg;
-        const double ghx = h0 * g.g0x + h1 * g.g1x + h2 * g.g2x, ghy = h0 * g.g0y + h1 * g.g1y + h2 * g.g2y;
+        const double zb0 = a.z_b[g.v0], zs0 = a.z_s[g.v0], N0 = a.N[g.v0];
+        const double dh1 = head_diff(a.z_b[g.v1] - zb0, a.z_s[g.v1] - zs0, a.N[g.v1] - N0, p);
+        const double dh2 = head_diff(a.z_b[g.v2] - zb0, a.z_s[g.v2] - zs0, a.N[g.v2] - N0, p);
+        const double ghx = dh1 * g.g1x + dh2 * g.g2x, ghy = dh1 * g.g1y + dh2 * g.g2y;
         const double b0 = a.b[g.v0], b1 = a.b[g.v1], b2 = a.b[g.v2];
-        const double gbx = b0 * g.g0x + b1 * g.g1x + b2 * g.g2x, gby = b0 * g.g0y + b1 * g.g1y + b2 * g.g2y;
+        const double gbx = (b1 - b0) * g.g1x + (b2 - b0) * g.g2x, gby = (b1 - b0) * g.g1y + (b2 - b0) * g.g2y;
         const double m0_ = a.melt_n[g.v0], m1_ = a.melt_n[g.v1], m2_ = a.melt_n[g.v2];
-        const double gmx = m0_ * g.g0x + m1_ * g.g1x + m2_ * g.g2x, gmy = m0_ * g.g0y + m1_ * g.g1y + m2_ * g.g2y;
+        const double gmx = (m1_ - m0_) * g.g1x + (m2_ - m0_) * g.g2x, gmy = (m1_ - m0_) * g.g1y + (m2_ - m0_) * g.g2y;
         const double bv = a.b[v], mv = a.melt_n[v];
         const double qxo = a.qx[v], qyo = a.qy[v];
         const double qn = sqrt(qxo * qxo + qyo * qyo);
@@ -667,9 +675,9 @@ __global__ __launch_bounds__(kBlock) void k_update_b(const UpdArgs a) {
     for (int64_t v = blockIdx.x * (int64_t)kBlock + threadIdx.x; v < a.nv; v += (int64_t)gridDim.x * kBlock) {
         const CellGeom g = cell_geom(a.m, a.lastcell[v]);
         const double b0 = a.b[g.v0], b1 = a.b[g.v1], b2 = a.b[g.v2];
-        const double gbx = b0 * g.g0x + b1 * g.g1x + b2 * g.g2x, gby = b0 * g.g0y + b1 * g.g1y + b2 * g.g2y;
+        const double gbx = (b1 - b0) * g.g1x + (b2 - b0) * g.g2x, gby = (b1 - b0) * g.g1y + (b2 - b0) * g.g2y;
         const double m0_ = a.melt_tmp[g.v0], m1_ = a.melt_tmp[g.v1], m2_ = a.melt_tmp[g.v2];
-        const double gmx = m0_ * g.g0x + m1_ * g.g1x + m2_ * g.g2x, gmy = m0_ * g.g0y + m1_ * g.g1y + m2_ * g.g2y;
+        const double gmx = (m1_ - m0_) * g.g1x + (m2_ - m0_) * g.g2x, gmy = (m1_ - m0_) * g.g1y + (m2_ - m0_) * g.g2y;
         const double bv = a.b[v], mv = a.melt_tmp[v], Nv = a.N[v];
         const double gb2 = gbx * gbx + gby * gby;
         const double melt = a.m0[v] + (mv * gb2 + bv * (gmx * gbx + gmy * gby)) / (1.0 + gb2);

@@ -175,4 +175,6 @@ def test_update_explicit_order_and_clamp():
     grads, _ = O.p1_geometry(dom.xy, dom.cells[last])
     gh = np.einsum("vi,vid->vd", O.head(f0.N, f0.z_b, f0.z_s, prm)[dom.cells[last]], grads)
     K = np.abs(f0.b) ** 3 * prm.g / (12 * prm.nu * (1 + prm.omega * np.hypot(f0.q[:, 0], f0.q[:, 1]) / prm.nu))
-    assert np.allclose(f.q, -K[:, None] * gh, rtol=1e-13, atol=0)
+    # (gh above differences nodal heads; the oracle differences each coefficient like FFCx: equal up to the
+    #  rounding of ~1e3 m heads over these cells)
+    assert np.allclose(f.q, -K[:, None] * gh, rtol=1e-10, atol=0)
