@@ -35,15 +35,20 @@ typedef struct shk_params {
     double g, rho_i, rho_w, nu, Lh, omega, n, A;
     double b_min;
     double newton_rtol, newton_atol, newton_relax;
-    double krylov_rtol, krylov_atol;
+    double krylov_rtol, krylov_atol;  /* target of every linear solve, on the TRUE residual ||F - J dx|| */
+    double krylov_fail_rtol;    /* a linear solve whose true relative residual ends above this (or is not finite) is a
+                                   FAILURE (shk_solve_info.krylov_failed); between krylov_rtol and this it has merely
+                                   stagnated at its fp64 floor eps * || |J| |dx| ||, which Newton absorbs.  Default 1e-6 */
     int32_t newton_max_it;
     int32_t krylov_max_it;
     int32_t krylov_check_every; /* iterations enqueued between host stop-flag polls; 0 = automatic */
-    int32_t precond;            /* SHK_PC_JACOBI (north_star's solver, default) or SHK_PC_AMG */
+    int32_t precond;            /* shk_precond; shk_default_params gives SHK_PC_JACOBI (north_star's solver), the Python
+                                   mirror and bench.py select SHK_PC_AMG */
 } shk_params;
 
-/* Right preconditioner of BiCGStab.  JACOBI is folded into the matrix (A D^-1).  AMG = one V(1,1) cycle of a
- * static-pattern aggregation multigrid (of the owned diagonal block on subdomain contexts). */
+/* Right preconditioner of BiCGStab.  JACOBI is folded into the matrix (A D^-1).  AMG = one V(0,2) cycle (two
+ * damped-Jacobi sweeps on the finest level on the way up, four Chebyshev-damped ones on every coarser level, no
+ * smoothing on the way down) of a static-pattern aggregation multigrid stored in float. */
 enum shk_precond {
     SHK_PC_JACOBI = 0,
     SHK_PC_AMG = 1,        /* on a communicator of > 1 subdomains: distributed hierarchy, built collectively by the
@@ -72,9 +77,10 @@ typedef struct shk_solve_info {
     int32_t newton_its;      /* NewtonSolver.solve's niter              (solvers.py:179) */
     int32_t converged;       /* ... and its converged flag */
     int32_t krylov_its;      /* BiCGStab iterations summed over the Newton iterations */
-    int32_t krylov_failed;   /* 1 if a linear solve hit max_it or broke down */
+    int32_t krylov_failed;   /* 1 if a linear solve ended above krylov_fail_rtol (max_it, breakdown, divergence) */
     double residual0;        /* ||F|| before the first Newton iteration */
     double residual;         /* ||F|| at exit */
+    double krylov_relres;    /* largest true relative residual ||F - J dx|| / ||F|| a linear solve of this call ended on */
 } shk_solve_info;
 
 /* Device-side timings accumulated with hipEvents on the library's stream while profiling is on. */
@@ -147,7 +153,8 @@ int shk_get_residual(shk_ctx* ctx, double* host);
 int shk_csr_nnz(shk_ctx* ctx, int64_t* nnz);
 int shk_get_csr(shk_ctx* ctx, int32_t* rowptr, int32_t* colidx, double* values);
 
-/* Solve J dx = F for the system last assembled (Jacobi-preconditioned BiCGStab); dx via SHK_DX. */
+/* Solve J dx = F for the system last assembled (BiCGStab with the right preconditioner shk_params.precond selects,
+ * wrapped in true-residual refinement); dx via SHK_DX.  converged = the true residual met krylov_rtol. */
 int shk_linear_solve(shk_ctx* ctx, int32_t* its, int32_t* converged, double* rel_residual);
 
 /* y = J x with the assembled Jacobian (unscaled) -- parity / roofline probe of the SpMV kernel. */

@@ -22,13 +22,14 @@ class ShaktiHipError(RuntimeError):
 class shk_params(C.Structure):
     _fields_ = [(n, C.c_double) for n in
                 ("g", "rho_i", "rho_w", "nu", "Lh", "omega", "n", "A", "b_min",
-                 "newton_rtol", "newton_atol", "newton_relax", "krylov_rtol", "krylov_atol")] + \
+                 "newton_rtol", "newton_atol", "newton_relax", "krylov_rtol", "krylov_atol", "krylov_fail_rtol")] + \
                [(n, C.c_int32) for n in ("newton_max_it", "krylov_max_it", "krylov_check_every", "precond")]
 
 
 class shk_solve_info(C.Structure):
     _fields_ = [("newton_its", C.c_int32), ("converged", C.c_int32), ("krylov_its", C.c_int32),
-                ("krylov_failed", C.c_int32), ("residual0", C.c_double), ("residual", C.c_double)]
+                ("krylov_failed", C.c_int32), ("residual0", C.c_double), ("residual", C.c_double),
+                ("krylov_relres", C.c_double)]
 
 
 PHASES = ("assemble", "spmv", "vector", "update", "other", "halo", "amg_fine", "amg_coarse", "amg_first")

@@ -222,6 +222,10 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
     if (const char* sa = getenv("SHK_AMG_ALPHA")) H.alpha = atof(sa);
     if (const char* sa = getenv("SHK_AMG_COARSE4")) H.coarse4 = atoi(sa) != 0;
     if (const char* sa = getenv("SHK_AMG_DENSE_PERIOD")) H.dense_period = std::max(1, atoi(sa));
+    if (const char* sa = getenv("SHK_AMG_DAMP_SCALE")) {   // robustness experiments: every damping of the cycle times f
+        const double f = atof(sa);
+        if (f > 0.0) { H.c1 *= f; H.c2 *= f; for (double& v : H.c4) v *= f; }
+    }
     if ((e = dev_alloc(c, &H.x0, (size_t)n_loc0)) != hipSuccess) return e;
     if ((e = dev_alloc(c, &H.x1, (size_t)n_loc0)) != hipSuccess) return e;
     if ((e = hipMemset(H.x1, 0, (size_t)n_loc0 * sizeof(float))) != hipSuccess) return e;
@@ -245,6 +249,7 @@ int shk_default_params(shk_params* p) {
     p->newton_rtol = 1e-9; p->newton_atol = 1e-10; p->newton_relax = 1.0; p->newton_max_it = 50;
     // the reference solves each Newton system exactly (LU); the Krylov loop is driven to 1e-10
     p->krylov_rtol = 1e-10; p->krylov_atol = 1e-50; p->krylov_max_it = 20000; p->krylov_check_every = 0;
+    p->krylov_fail_rtol = 1e-6;
     p->precond = SHK_PC_JACOBI;
     return 0;
 }
@@ -395,6 +400,7 @@ int shk_set_params(shk_ctx* ctx, const shk_params* p) {
     if (!p) return fail("null params");
     if (!(p->g > 0 && p->rho_i > 0 && p->rho_w > 0 && p->nu > 0 && p->Lh > 0)) return fail("non-positive constant");
     if (p->newton_max_it < 0 || p->krylov_max_it < 1 || p->krylov_check_every < 0) return fail("bad iteration limits");
+    if (!(p->krylov_fail_rtol >= 0)) return fail("krylov_fail_rtol must be >= 0");
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (p->precond != SHK_PC_JACOBI && p->precond != SHK_PC_AMG && p->precond != SHK_PC_AMG_LOCAL)
         return fail("unknown preconditioner id");
@@ -691,9 +697,13 @@ int shk_newton_solve(shk_ctx* ctx, double dt, shk_solve_info* info) {
     bool conv = r < c->params.newton_atol;  // relative residual is 1 at iteration 0
     while (!conv && it < c->params.newton_max_it) {
         int k = 0, kc = 0;
-        if (krylov_solve(c, &k, &kc, nullptr, it == 0)) return -1;
+        double rr = 0.0;
+        if (krylov_solve(c, &k, &kc, &rr, it == 0)) return -1;
         I.krylov_its += k;
-        if (!kc) I.krylov_failed = 1;
+        // a solve that stagnated between krylov_rtol and krylov_fail_rtol sits on its fp64 floor
+        // eps || |J| |dx| || (Newton absorbs it); beyond that -- max_it, breakdown, divergence -- it has failed
+        if (!kc && !(rr <= std::max(c->params.krylov_rtol, c->params.krylov_fail_rtol))) I.krylov_failed = 1;
+        if (!(rr <= I.krylov_relres)) I.krylov_relres = rr;   // also keeps a NaN
         launch_newton_update(c, true);
         HIPCHK(halo_exchange(c, c->f[SHK_N]));
         launch_assemble(c, dt);

@@ -97,8 +97,88 @@ def read_msh(path: str) -> Domain:
     return Domain(xy, cells.astype(np.int32), h=float(np.sqrt(np.abs(det).mean())), meta=dict(source=path))
 
 
+def _boundary_loops(dom: Domain):
+    """Closed chains of boundary vertices (one list per boundary loop)."""
+    bf = dom.boundary_facets()
+    nxt = {}
+    for a, b in bf:
+        nxt.setdefault(int(a), []).append(int(b))
+        nxt.setdefault(int(b), []).append(int(a))
+    seen, loops = set(), []
+    for start in sorted(nxt):
+        if start in seen:
+            continue
+        loop, prev, cur = [start], None, start
+        seen.add(start)
+        while True:
+            cand = [v for v in nxt[cur] if v != prev and (v not in seen or (v == start and len(loop) > 2))]
+            if not cand or cand[0] == start:
+                break
+            prev, cur = cur, cand[0]
+            seen.add(cur)
+            loop.append(cur)
+        loops.append(loop)
+    return loops
+
+
+def _write_msh41_entities(path: str, dom: Domain, tag_stride: int = 3) -> None:
+    """Gmsh 4.1 ASCII in the layout Gmsh itself produces for a meshed surface with physical groups: $PhysicalNames,
+    $Entities, node blocks per entity (boundary curves first, then the surface; non-contiguous node tags), line
+    elements on the boundary curves, one point element, and the triangles in the surface block."""
+    nv, ne = dom.num_vertices, dom.num_cells
+    loops = _boundary_loops(dom)
+    on_bdry = np.zeros(nv, dtype=bool)
+    for lp in loops:
+        on_bdry[lp] = True
+    tag = np.zeros(nv, dtype=np.int64)      # node tags: boundary nodes first, stride > 1 (tags need not be dense)
+    order = [v for lp in loops for v in lp] + [int(v) for v in np.nonzero(~on_bdry)[0]]
+    for k, v in enumerate(order):
+        tag[v] = 1 + tag_stride * k
+    lo, hi = dom.xy.min(axis=0), dom.xy.max(axis=0)
+    box = f"{float(lo[0])!r} {float(lo[1])!r} 0 {float(hi[0])!r} {float(hi[1])!r} 0"
+    nl = len(loops)
+    with open(path, "w") as f:
+        f.write("$MeshFormat\n4.1 0 8\n$EndMeshFormat\n")
+        f.write(f"$PhysicalNames\n2\n1 1 \"boundary\"\n2 2 \"ice\"\n$EndPhysicalNames\n")
+        f.write(f"$Entities\n1 {nl} 1 0\n")
+        x0, y0 = dom.xy[loops[0][0]]
+        f.write(f"1 {float(x0)!r} {float(y0)!r} 0 0\n")
+        for c in range(nl):
+            f.write(f"{c + 1} {box} 1 1 0\n")
+        f.write(f"1 {box} 1 2 {nl} " + " ".join(str(c + 1) for c in range(nl)) + "\n$EndEntities\n")
+        n_int = int((~on_bdry).sum())
+        f.write(f"$Nodes\n{nl + 2} {nv} 1 {int(tag.max())}\n")
+        f.write("0 1 0 0\n")                          # the geometry point carries no mesh node of its own here
+        for c, lp in enumerate(loops):
+            f.write(f"1 {c + 1} 0 {len(lp)}\n")
+            f.writelines(f"{tag[v]}\n" for v in lp)
+            f.writelines(f"{float(dom.xy[v, 0])!r} {float(dom.xy[v, 1])!r} 0\n" for v in lp)
+        inner = np.nonzero(~on_bdry)[0]
+        f.write(f"2 1 0 {n_int}\n")
+        f.writelines(f"{tag[v]}\n" for v in inner)
+        f.writelines(f"{float(dom.xy[v, 0])!r} {float(dom.xy[v, 1])!r} 0\n" for v in inner)
+        f.write("$EndNodes\n")
+        nlines = sum(len(lp) for lp in loops)
+        f.write(f"$Elements\n{nl + 2} {1 + nlines + ne} 1 {1 + nlines + ne}\n")
+        f.write(f"0 1 15 1\n1 {tag[loops[0][0]]}\n")
+        eid = 2
+        for c, lp in enumerate(loops):
+            f.write(f"1 {c + 1} 1 {len(lp)}\n")
+            for k, v in enumerate(lp):
+                f.write(f"{eid} {tag[v]} {tag[lp[(k + 1) % len(lp)]]}\n")
+                eid += 1
+        f.write(f"2 1 2 {ne}\n")
+        for c in dom.cells:
+            f.write(f"{eid} {tag[c[0]]} {tag[c[1]]} {tag[c[2]]}\n")
+            eid += 1
+        f.write("$EndElements\n")
+
+
 def write_msh(path: str, dom: Domain, version: str = "2.2") -> None:
-    """Minimal ASCII writer (tests, and handing synthetic meshes to Gmsh-based tools)."""
+    """ASCII writer (tests, and handing synthetic meshes to Gmsh-based tools).  version "2.2" | "4.1" (one node and
+    one element block) | "4.1-entities" (entity blocks, physical groups, boundary line elements, sparse node tags)."""
+    if version == "4.1-entities":
+        return _write_msh41_entities(path, dom)
     nv, ne = dom.num_vertices, dom.num_cells
     with open(path, "w") as f:
         if version.startswith("2"):

@@ -71,6 +71,9 @@ class SingleRunner:
         i = self.next_step if i is None else i
         dt = 0.1 * self.dt if i == 0 else self.dt  # solvers.py:81,174-176
         info = self.ctx.step(dt)
+        if info.krylov_failed:
+            raise RuntimeError(f"linear solve failed at step {i}: true relative residual {info.krylov_relres:.3e} after "
+                               f"{info.krylov_its} BiCGStab iterations")
         if not info.converged:
             raise RuntimeError(f"Newton did not converge at step {i}: residual {info.residual:g} "
                                f"after {info.newton_its} iterations")  # error_on_nonconvergence=True

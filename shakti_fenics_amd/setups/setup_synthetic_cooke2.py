@@ -12,9 +12,14 @@ from shakti_fenics_amd.params import g, rho_i, rho_w
 from shakti_fenics_amd.synthetic import bed, surface
 
 
-def initialize(comm, nx=71, ny=71, L=100e3, days=10.0 / 24.0, results_root=None, ingest="device"):
+def initialize(comm, nx=71, ny=71, L=100e3, days=10.0 / 24.0, results_root=None, ingest="device", mesh_file=None):
     lake_name = "Synthetic_E2"
-    domain = rectangle_mesh(nx, ny, L, L, jitter=0.25, seed=1234)       # C1 of SURVEY.md 8d
+    if mesh_file:                                                       # setup_cooke2.py:19 (gmshio.read_from_msh)
+        from shakti_fenics_amd.gmsh_io import read_msh
+        domain = read_msh(mesh_file)
+        L = float(max(domain.xy[:, 0].max(), domain.xy[:, 1].max()))
+    else:
+        domain = rectangle_mesh(nx, ny, L, L, jitter=0.25, seed=1234)   # C1 of SURVEY.md 8d
     md = model_setup(comm, domain)
     md.ingest = ingest   # "device": interp_data / set_lake_bdry on the GPU; "host": the reference's scipy path
     md.setup_name = os.path.splitext(os.path.basename(__file__))[0]
@@ -26,7 +31,9 @@ def initialize(comm, nx=71, ny=71, L=100e3, days=10.0 / 24.0, results_root=None,
 
     # lake outline: a disc of radius 5 km at the domain centre, as a polygon
     th = np.linspace(0, 2 * np.pi, 65)[:-1]
-    md.outline = np.column_stack((0.5 * L + 5e3 * np.cos(th), 0.5 * L + 5e3 * np.sin(th)))
+    cx, cy = 0.5 * (domain.xy[:, 0].min() + domain.xy[:, 0].max()), 0.5 * (domain.xy[:, 1].min() + domain.xy[:, 1].max())
+    r_lake = min(5e3, 0.2 * L)
+    md.outline = np.column_stack((cx + r_lake * np.cos(th), cy + r_lake * np.sin(th)))
     md.set_lake_bdry(md.outline)
 
     # geometry on regular grids, pushed through the same interp_data path as the reference's NetCDF data

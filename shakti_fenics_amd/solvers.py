@@ -69,9 +69,18 @@ class NewtonSolverHIP:
         info = c.newton_solve(float(self.dt))
         N.x.array[:] = c.get_field("N")
         self.krylov_iterations = info.krylov_its
+        if info.krylov_failed:
+            raise RuntimeError(_krylov_failure_text(info))
         if not info.converged and self.error_on_nonconvergence:
             raise RuntimeError("Newton solver did not converge")  # DOLFINx raises as well
         return info.newton_its, bool(info.converged)
+
+
+def _krylov_failure_text(info, step=None):
+    where = "" if step is None else f" at time step {step}"
+    return (f"linear solve failed{where}: true relative residual {info.krylov_relres:.3e} after {info.krylov_its} BiCGStab "
+            "iterations (iteration limit, breakdown or a diverging preconditioner); the reference's sparse LU has no "
+            "such failure mode, so this is an error, not a result")
 
 
 def pde_solver(md, N, N_n, b, q, melt_n, storage, dt):
@@ -220,6 +229,9 @@ def solve(md):
             break
         info = ctx.step(dt.value)          # Newton solve + q, melt_n, b updates + N_n <- N, all on the GPU
         newton_log[i], krylov_log[i] = info.newton_its, info.krylov_its
+        if info.krylov_failed:
+            ctx.close()
+            raise RuntimeError(_krylov_failure_text(info, i))
         if not info.converged:
             ctx.close()
             raise RuntimeError(f"Newton solver did not converge at time step {i}")

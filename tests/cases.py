@@ -2,15 +2,17 @@
 import numpy as np
 
 import shakti_oracle as O
-from shakti_fenics_amd.mesh import rectangle_mesh
+from shakti_fenics_amd.mesh import basin_mesh, rectangle_mesh
 from shakti_fenics_amd.synthetic import N_BDRY, outflow_predicate, synthetic_fields
 
 
 def make_case(nx=31, ny=23, Lx=10e3, Ly=8e3, order="morton", storage_on=True, raw_b=False, moulins=0,
-              perturb=False, seed=5):
+              perturb=False, seed=5, basin=0):
     """Mesh + oracle Fields + Dirichlet dofs.  perturb=True puts every field in a generic state
-    (N away from N_n, q and melt_n non-zero) so that every term of the form is exercised."""
-    dom = rectangle_mesh(nx, ny, Lx, Ly, order=order)
+    (N away from N_n, q and melt_n non-zero) so that every term of the form is exercised.
+    basin=n: the unstructured Delaunay basin mesh of about n vertices (hole, curved outlet, valence 13) instead
+    of the jittered rectangle; its outlet is the arc x < 0."""
+    dom = basin_mesh(basin, order=order) if basin else rectangle_mesh(nx, ny, Lx, Ly, order=order)
     sf = synthetic_fields(dom, storage_on=storage_on, moulins=moulins)
     nv = dom.num_vertices
     b = sf["b_init"] if raw_b else np.abs(sf["b_init"])
@@ -24,7 +26,7 @@ def make_case(nx=31, ny=23, Lx=10e3, Ly=8e3, order="morton", storage_on=True, ra
         f.melt_n = 1e-7 * rng.uniform(size=nv)
         f.storage = rng.uniform(size=nv) * (rng.uniform(size=nv) < 0.5)
         f.inputs = 1e-9 * rng.uniform(size=nv)
-    bc = O.boundary_dofs(dom.xy, dom.cells, outflow_predicate(dom))
+    bc = O.boundary_dofs(dom.xy, dom.cells, (lambda X: X[0] < 1e-9) if basin else outflow_predicate(dom))
     return dom, f, bc, N_BDRY
 
 

@@ -52,7 +52,8 @@ int main(int argc, char** argv) {
     const std::string err = build_plan(nv, nv, ne, xy.data(), cells.data(), opt, P);
     CHECK("build_plan", err.empty());
     if (!err.empty()) { std::printf("error %s\n", err.c_str()); return 1; }
-    std::printf("nnz %lld\nslots %lld\nlevels %zu\n", (long long)P.A.nnz, (long long)P.A.slots, P.amg.size());
+    std::printf("nnz %lld\nslots %lld\nlevels %zu\nmax_row_len %d\n", (long long)P.A.nnz, (long long)P.A.slots, P.amg.size(),
+                P.A.max_row_len);
 
     // permutation is a bijection; SELL rows hold the diagonal first and distinct columns
     {

@@ -55,8 +55,19 @@ def floor_probe(r, dt, nsample=3000, seed=3):
     Fx = np.zeros(verts.size, dtype=ld)
     np.add.at(Fx, cc.ravel(), Fe.ravel())
     d = (F[sample].astype(ld) - Fx[loc[sample]]).astype(np.float64)
+    # Sensitivity of F to the fp64 REPRESENTATION of the unknown: move every free N by one ulp (random sign) and
+    # re-assemble.  Rounding N - dx to fp64 perturbs N by <= 0.5 ulp (rms ulp / sqrt(12)), so no solver that stores
+    # N in fp64 -- DOLFINx/PETSc included -- can drive ||F|| below about  sens / sqrt(12).
+    N0 = host["N"]
+    sgn = np.random.default_rng(seed + 1).choice([-1.0, 1.0], nv)
+    sgn[isbc] = 0.0
+    c.set_field("N", N0 + np.spacing(N0) * sgn)
+    c.assemble(dt)
+    sens = float(np.linalg.norm(c.residual() - F))
+    c.set_field("N", N0)
     return dict(floor=float(np.sqrt(nv / sample.size) * np.linalg.norm(d)), worst_entry=float(np.abs(d).max()),
-                sampled_rows=int(sample.size), norm_F=float(np.linalg.norm(F)))
+                sampled_rows=int(sample.size), norm_F=float(np.linalg.norm(F)), one_ulp_N_sensitivity=sens,
+                representation_floor=sens / np.sqrt(12.0), b_max=float(host["b"].max()))
 
 
 def main():
