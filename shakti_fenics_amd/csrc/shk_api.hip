@@ -279,6 +279,8 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
     PlanOptions opt;
     if (const char* s = getenv("SHK_ASM_SLICES")) opt.slices_max = std::max(1, atoi(s));
     if (const char* s = getenv("SHK_ASM_CELLS")) opt.cells_max = std::max(64, atoi(s));
+    opt.cells_max = std::min(opt.cells_max, kAsmCellsMax);
+    if (const char* s = getenv("SHK_ASM_THREADS")) c->asm_threads = atoi(s) == 512 ? 512 : 256;
     if (const char* s = getenv("SHK_SORT_WINDOW")) opt.sort_window = std::max(64, atoi(s));
     if (const char* s = getenv("SHK_REORDER")) opt.reorder = atoi(s) != 0;
     if (const char* s = getenv("SHK_AMG")) opt.amg = atoi(s) != 0;
@@ -292,13 +294,8 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
     c->cells_staged = (int64_t)P.blk_cells.size();
     c->grid = (int)std::min<int64_t>(kMaxParts, std::max<int64_t>(1, (c->n_own + kBlock - 1) / kBlock));
     c->np = c->grid;
-    {
-        const size_t E = P.cells_max, S = P.slices_max;
-        size_t lds = 12 * E * sizeof(double) + (S + 1) * sizeof(int) +
-                     (S * kSlice + 1) * sizeof(int) + (size_t)P.max_inc_per_block * sizeof(uint16_t);
-        c->asm_lds = (lds + 15) & ~size_t(15);
-        if (c->asm_lds > 160 * 1024) { delete c; return fail("assembly LDS budget exceeds 160 KiB"); }
-    }
+    c->asm_lds = assemble_lds_bytes(P, &c->asm_region_a);
+    if (c->asm_lds > 160 * 1024) { delete c; return fail("assembly LDS budget exceeds 160 KiB"); }
     auto bail = [&](hipError_t e, const char* what) {
         std::string m = std::string(what) + ": " + hipGetErrorString(e);
         shk_destroy(reinterpret_cast<shk_ctx*>(c));
@@ -317,12 +314,15 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
     UP(d_cells, cells); UP(d_perm, perm); UP(d_sell_ptr, A.ptr); UP(d_sell_col, A.col); UP(d_rowlen, A.rowlen);
     UP(d_cbase, A.cbase); UP(d_ptr16, A.ptr16); UP(d_col16, A.col16);
     UP(d_lastcell, lastcell); UP(d_blk_slice0, blk_slice0); UP(d_blk_cellptr, blk_cellptr);
-    UP(d_blk_cells, blk_cells); UP(d_incptr, incptr); UP(d_inccode, inccode); UP(d_slotsrc, slotsrc);
+    UP(d_blk_haloptr, blk_haloptr); UP(d_blk_halo, blk_halo); UP(d_blk_cellv, blk_cellv);
+    UP(d_incptr, incptr); UP(d_inccode, inccode); UP(d_slotsrc, slotsrc);
 #undef UP
     // the host copies of the big plan arrays are no longer needed (the SELL pattern stays for get_csr)
     c->plan.xy = std::vector<double>();
     c->plan.cells = std::vector<int32_t>();
     c->plan.blk_cells = std::vector<int32_t>();
+    c->plan.blk_halo = std::vector<int32_t>();
+    c->plan.blk_cellv = std::vector<uint16_t>();
     c->plan.inccode = std::vector<uint16_t>();
     c->plan.slotsrc = std::vector<uint32_t>();
     c->plan.incptr = std::vector<int32_t>();
@@ -346,8 +346,6 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
     if ((e = hipMemset(c->d_dinv32, 0, nl * sizeof(float))) != hipSuccess) return bail(e, "memset");
     if ((e = dev_alloc(c, &c->d_bcflag, nl)) != hipSuccess) return bail(e, "alloc bcflag");
     if ((e = hipMemset(c->d_bcflag, 0, nl)) != hipSuccess) return bail(e, "memset");
-    if ((e = dev_alloc(c, &c->d_slotbc, (size_t)c->slots)) != hipSuccess) return bail(e, "alloc slotbc");
-    if ((e = hipMemset(c->d_slotbc, 0, (size_t)c->slots)) != hipSuccess) return bail(e, "memset");
     if ((e = dev_alloc(c, &c->d_part, (size_t)P_COUNT * kMaxParts)) != hipSuccess) return bail(e, "alloc partials");
     if ((e = hipMemset(c->d_part, 0, P_COUNT * kMaxParts * sizeof(double))) != hipSuccess) return bail(e, "memset");
     c->d_red = c->d_part;
@@ -490,8 +488,7 @@ int shk_set_dirichlet(shk_ctx* ctx, int64_t n, const int32_t* dofs, double value
         flag[c->plan.iperm[dofs[i]]] = 1;
     }
     HIPCHK(hipMemcpy(c->d_bcflag, flag.data(), (size_t)c->n_loc, hipMemcpyHostToDevice));
-    HIPCHK(hipMemsetAsync(c->d_slotbc, 0, (size_t)c->slots, c->stream));
-    if (n > 0) launch_slot_bc(c);
+    launch_slot_bc(c);   // per-slot Dirichlet codes into the plan words (all zero when n == 0)
     HIPCHK(hipStreamSynchronize(c->stream));
     c->has_bc = n > 0;
     c->bc_value = value;

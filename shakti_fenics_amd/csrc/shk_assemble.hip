@@ -1,0 +1,388 @@
+// k_assemble: fused residual + Jacobian of the weak form at /root/reference/source/solvers.py:35-45 with the closures
+// of constitutive.py:6-31 and DOLFINx's Dirichlet algebra, atomic-free and bitwise reproducible.
+//
+// One workgroup owns up to 4 SELL slices = 256 consecutive rows (a compact patch of the k-d order) and runs
+//   phase 0  stages the 13 nodal doubles (x, y and the 11 fields) of its vertices in LDS: its own rows with fully
+//            coalesced loads (they are consecutive), the halo vertices of its cells (~0.5 per own row) through a
+//            per-block gather list.  Workgroups are dealt to the XCDs so that each XCD sweeps one contiguous range
+//            of patches: neighbouring patches then share an L2, which serves most halo gathers.
+//   phase 1  one thread per cell touching the owned rows (cells named by 3 x 16-bit LOCAL vertex ids: one coalesced
+//            8-byte load per cell, no dependent global gathers): 15-point degree-7 rule for the transmissivity
+//            integral, 7-point degree-5 rule for every polynomial term, both fully unrolled with their tables
+//            broadcast from LDS; the 3x3 + 3 element tensor stays in registers until every thread has read its
+//            fields, then replaces them in the SAME LDS region (61 KB per workgroup instead of 100).
+//   phase 2  one thread per SELL slot: an off-diagonal entry adds its <= 2 staged cells named by the plan (4 B per
+//            slot, which also carries the slot's Dirichlet code), the diagonal and the residual row sum their
+//            incidence list in ascending cell order.  Every value is written exactly once, coalesced.
+#include "shk_device.h"
+
+namespace shk {
+
+#ifndef SHK_UNROLL_Q
+#define SHK_UNROLL_Q 5   // independent quadrature points in flight (registers against ILP at 2 waves per SIMD)
+#endif
+#ifndef SHK_UNROLL_P
+#define SHK_UNROLL_P 7
+#endif
+#ifndef SHK_ASM_WAVES
+#define SHK_ASM_WAVES 2
+#endif
+constexpr int kAsmFields = 13;   // x, y, N, N_n, b, qx, qy, z_b, z_s, G, melt_n, storage, inputs
+enum { AF_X = 0, AF_Y, AF_N, AF_NN, AF_B, AF_QX, AF_QY, AF_ZB, AF_ZS, AF_G, AF_M, AF_S, AF_I };
+
+struct QPoint { double f0, f1, f2, w; };   // barycentric weights of a quadrature point and 2 * its weight
+
+// Difference of the head between two vertices from the differences of its coefficients (constitutive.py:6-9).
+// Like FFCx, every coefficient is differenced on its own (reference gradient = nodal differences f1 - f0, f2 - f0):
+// rounding is then relative to the differences, not to the head's magnitude (~1e3 m over cells of ~10 m), which
+// puts the fp64 floor of ||F|| three orders of magnitude below what differencing nodal heads gives.
+__device__ __forceinline__ double head_diff(double dzb, double dzs, double dN, const DevParams& p) {
+    return dzb + p.ri_rw * (dzs - dzb) - dN / p.rwg;
+}
+
+// sqrt(s) for s >= 0 well inside the double range (|q|^2): rsq + the compiler's own refinement, without its
+// range scaling.  ~1 ulp.
+__device__ __forceinline__ double sqrt_nn(double s) {
+    const double y = __builtin_amdgcn_rsq(s);
+    double g = s * y, h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    g = __builtin_fma(__builtin_fma(-g, g, s), h, g);
+    g = __builtin_fma(__builtin_fma(-g, g, s), h, g);
+    return s > 0.0 ? g : 0.0;
+}
+// a / d for 1 <= d << 1e300: rcp + two Newton steps + one residual correction.  ~1 ulp.
+__device__ __forceinline__ double div_ge1(double a, double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    const double q = a * r;
+    return __builtin_fma(__builtin_fma(-d, q, a), r, q);
+}
+
+// XCD-aware block map (MI355X: workgroups are dealt round-robin to 8 XCDs with private L2s): XCD x sweeps the
+// contiguous block range [start(x), start(x+1)).  Placement changes speed only.
+__device__ __forceinline__ int xcd_block(int b, int nb) {
+    const int per = nb >> 3, rem = nb & 7, x = b & 7, i = b >> 3;
+    return x * per + min(x, rem) + i;
+}
+
+struct CellOut { double K[9], F[3]; };
+
+template <int NQ, int NP>
+__device__ __forceinline__ void cell_tensor(const AsmArgs& a, const double* __restrict__ fld, const uint8_t* __restrict__ bcf,
+                                            const QPoint* __restrict__ qk, const QPoint* __restrict__ qp, int V,
+                                            int l0, int l1, int l2, CellOut& o) {
+    const DevParams& p = a.p;
+#define LD(k, l) fld[(k) * V + (l)]
+    const double x0 = LD(AF_X, l0), y0 = LD(AF_Y, l0);
+    const double d1x = LD(AF_X, l1) - x0, d1y = LD(AF_Y, l1) - y0, d2x = LD(AF_X, l2) - x0, d2y = LD(AF_Y, l2) - y0;
+    const double det = d1x * d2y - d1y * d2x;
+    const double inv = 1.0 / det;
+    const double area = 0.5 * fabs(det);
+    const double g1x = d2y * inv, g1y = -d2x * inv, g2x = -d1y * inv, g2y = d1x * inv;
+    const double g0x = -(g1x + g2x), g0y = -(g1y + g2y);
+
+    const double b0 = LD(AF_B, l0), b1 = LD(AF_B, l1), b2 = LD(AF_B, l2);
+    const double qx0 = LD(AF_QX, l0), qx1 = LD(AF_QX, l1), qx2 = LD(AF_QX, l2);
+    const double qy0 = LD(AF_QY, l0), qy1 = LD(AF_QY, l1), qy2 = LD(AF_QY, l2);
+    // WaterFlux with the Reynolds switch, constitutive.py:11-20: q_w = -K grad(h); sK = int K dx
+    double sK = 0.0;
+    auto flux_point = [&](int k) {
+        const QPoint q = qk[k];
+        const double bk = b0 * q.f0 + b1 * q.f1 + b2 * q.f2;
+        const double qxk = qx0 * q.f0 + qx1 * q.f1 + qx2 * q.f2;
+        const double qyk = qy0 * q.f0 + qy1 * q.f1 + qy2 * q.f2;
+        const double qn = sqrt_nn(qxk * qxk + qyk * qyk);
+        const double ab = fabs(bk);
+        sK += div_ge1(q.w * (ab * ab * ab), 1.0 + p.om_nu * qn);
+    };
+    if constexpr (NQ > 0) {
+#pragma unroll SHK_UNROLL_Q
+        for (int k = 0; k < NQ; ++k) flux_point(k);
+    } else {
+        for (int k = 0; k < a.quad.nq; ++k) flux_point(k);
+    }
+    sK *= area * p.kcoef;
+
+    const double N0 = LD(AF_N, l0), N1 = LD(AF_N, l1), N2 = LD(AF_N, l2);
+    const double m0_ = LD(AF_M, l0), m1_ = LD(AF_M, l1), m2_ = LD(AF_M, l2);
+    const double zb0 = LD(AF_ZB, l0), zs0 = LD(AF_ZS, l0);
+    const double dh1 = head_diff(LD(AF_ZB, l1) - zb0, LD(AF_ZS, l1) - zs0, N1 - N0, p);
+    const double dh2 = head_diff(LD(AF_ZB, l2) - zb0, LD(AF_ZS, l2) - zs0, N2 - N0, p);
+    const double ghx = dh1 * g1x + dh2 * g2x, ghy = dh1 * g1y + dh2 * g2y;
+    const double gbx = (b1 - b0) * g1x + (b2 - b0) * g2x, gby = (b1 - b0) * g1y + (b2 - b0) * g2y;
+    const double gmx = (m1_ - m0_) * g1x + (m2_ - m0_) * g2x, gmy = (m1_ - m0_) * g1y + (m2_ - m0_) * g2y;
+    const double gb2 = gbx * gbx + gby * gby;
+    const double inv_den = 1.0 / (1.0 + gb2);
+    const double gmgb = gmx * gbx + gmy * gby;
+    const double Nn0 = LD(AF_NN, l0), Nn1 = LD(AF_NN, l1), Nn2 = LD(AF_NN, l2);
+    const double G0 = LD(AF_G, l0), G1 = LD(AF_G, l1), G2 = LD(AF_G, l2);
+    const double s0 = LD(AF_S, l0), s1 = LD(AF_S, l1), s2 = LD(AF_S, l2);
+    const double i0 = LD(AF_I, l0), i1 = LD(AF_I, l1), i2 = LD(AF_I, l2);
+#undef LD
+
+    double F0 = 0.0, F1 = 0.0, F2 = 0.0;
+    double T00 = 0.0, T01 = 0.0, T02 = 0.0, T11 = 0.0, T12 = 0.0, T22 = 0.0;
+    const double qgh0 = p.rwg * (qx0 * ghx + qy0 * ghy), qgh1 = p.rwg * (qx1 * ghx + qy1 * ghy),
+                 qgh2 = p.rwg * (qx2 * ghx + qy2 * ghy);  // rho_w g q.grad(h) is P1: interpolate its nodal values
+    auto poly_point = [&](int k) {
+        const QPoint q = qp[k];
+        const double f0 = q.f0, f1 = q.f1, f2 = q.f2;
+        const double w = q.w * area;
+        const double Nk = N0 * f0 + N1 * f1 + N2 * f2;
+        const double Nnk = Nn0 * f0 + Nn1 * f1 + Nn2 * f2;
+        const double bk = b0 * f0 + b1 * f1 + b2 * f2;
+        const double Gk = G0 * f0 + G1 * f1 + G2 * f2;
+        const double mk = m0_ * f0 + m1_ * f1 + m2_ * f2;
+        const double sk = s0 * f0 + s1 * f1 + s2 * f2;
+        const double ik = i0 * f0 + i1 * f1 + i2 * f2;
+        const double qghk = qgh0 * f0 + qgh1 * f1 + qgh2 * f2;
+        // Melt, constitutive.py:22-27 (div of the cell-wise P1 product expanded)
+        const double melt = (Gk - qghk) / p.Lh + (mk * gb2 + bk * gmgb) * inv_den;
+        const double pw = p.n_is_3 ? Nk * Nk : pow(fabs(Nk), p.n - 1.0);   // |N|^(n-1), constitutive.py:31
+        const double closure = p.A * bk * Nk * pw;                 // constitutive.py:29-31
+        const double stor = sk * (Nk - Nnk) * a.inv_rwg_dt;        // solvers.py:42
+        const double ws = w * (p.c_m * melt - closure - stor - ik);
+        F0 += ws * f0; F1 += ws * f1; F2 += ws * f2;
+        const double wd = w * (p.A * p.n * bk * pw + sk * a.inv_rwg_dt);
+        T00 += wd * f0 * f0; T01 += wd * f0 * f1; T02 += wd * f0 * f2;
+        T11 += wd * f1 * f1; T12 += wd * f1 * f2; T22 += wd * f2 * f2;
+    };
+    if constexpr (NP > 0) {
+#pragma unroll SHK_UNROLL_P
+        for (int k = 0; k < NP; ++k) poly_point(k);
+    } else {
+        for (int k = 0; k < a.qpoly.nq; ++k) poly_point(k);
+    }
+    // flux term: K grad(h).grad(phi_i)
+    double Fe0 = sK * (ghx * g0x + ghy * g0y) + F0;
+    double Fe1 = sK * (ghx * g1x + ghy * g1y) + F1;
+    double Fe2 = sK * (ghx * g2x + ghy * g2y) + F2;
+    const double kk = -sK / p.rwg;
+    const double d00 = g0x * g0x + g0y * g0y, d01 = g0x * g1x + g0y * g1y, d02 = g0x * g2x + g0y * g2y;
+    const double d11 = g1x * g1x + g1y * g1y, d12 = g1x * g2x + g1y * g2y, d22 = g2x * g2x + g2y * g2y;
+    // int phi_i q_x dx = area/12 (sum q_x + q_x,i): exact P1 mass matrix
+    const double cq = p.c_m / p.Lh * area * (1.0 / 12.0);
+    const double sx = qx0 + qx1 + qx2, sy = qy0 + qy1 + qy2;
+    const double Px0 = cq * (sx + qx0), Px1 = cq * (sx + qx1), Px2 = cq * (sx + qx2);
+    const double Py0 = cq * (sy + qy0), Py1 = cq * (sy + qy1), Py2 = cq * (sy + qy2);
+    o.K[0] = kk * d00 + (Px0 * g0x + Py0 * g0y) - T00;
+    o.K[1] = kk * d01 + (Px0 * g1x + Py0 * g1y) - T01;
+    o.K[2] = kk * d02 + (Px0 * g2x + Py0 * g2y) - T02;
+    o.K[3] = kk * d01 + (Px1 * g0x + Py1 * g0y) - T01;
+    o.K[4] = kk * d11 + (Px1 * g1x + Py1 * g1y) - T11;
+    o.K[5] = kk * d12 + (Px1 * g2x + Py1 * g2y) - T12;
+    o.K[6] = kk * d02 + (Px2 * g0x + Py2 * g0y) - T02;
+    o.K[7] = kk * d12 + (Px2 * g1x + Py2 * g1y) - T12;
+    o.K[8] = kk * d22 + (Px2 * g2x + Py2 * g2y) - T22;
+    const int bc0 = bcf[l0], bc1 = bcf[l1], bc2 = bcf[l2];
+    if (bc0 | bc1 | bc2) {
+        // apply_lifting(alpha=-1): F_i += K_ij (g - N_j) over Dirichlet columns j
+        const double e0 = bc0 ? a.bc_value - N0 : 0.0;
+        const double e1 = bc1 ? a.bc_value - N1 : 0.0;
+        const double e2 = bc2 ? a.bc_value - N2 : 0.0;
+        Fe0 += o.K[0] * e0 + o.K[1] * e1 + o.K[2] * e2;
+        Fe1 += o.K[3] * e0 + o.K[4] * e1 + o.K[5] * e2;
+        Fe2 += o.K[6] * e0 + o.K[7] * e1 + o.K[8] * e2;
+    }
+    o.F[0] = Fe0; o.F[1] = Fe1; o.F[2] = Fe2;
+}
+
+// T threads per workgroup; NQ / NP: points of the two rules when they are the built-in ones (15 / 7: loops fully
+// unrolled), 0 = run-time counts (a user table from shk_set_quadrature, or Glen's n != 3).
+template <int T, int NQ, int NP>
+__global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) {
+    constexpr int R = (kAsmCellsMax + T - 1) / T;   // cells per thread
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int E = a.cells_max, V = a.verts_max;
+    double* fld = reinterpret_cast<double*>(smem);                  // [13][V] staged fields ...
+    double* et = fld;                                               // ... later [12][E] element tensors (same region)
+    QPoint* qk = reinterpret_cast<QPoint*>(smem + a.lds_region_a);
+    QPoint* qp = qk + kMaxQuad;
+    int* sp = reinterpret_cast<int*>(qp + kMaxQuad);                // [slices_max+1] SELL ptr of owned slices
+    int* ip = sp + (a.slices_max + 1);                              // [rows+1] incptr of owned rows
+    uint16_t* ic = reinterpret_cast<uint16_t*>(ip + (a.slices_max * kSlice + 1));  // incidence codes
+    uint8_t* bcf = reinterpret_cast<uint8_t*>(ic + a.inc_max);      // [V] Dirichlet flags of the staged vertices
+
+    const int blk = xcd_block(blockIdx.x, gridDim.x);
+    const int tid = threadIdx.x;
+    const int s0 = a.blk_slice0[blk], ns = a.blk_slice0[blk + 1] - s0;
+    const int r0 = s0 * kSlice;
+    const int r1 = min(a.A.n_rows, (s0 + ns) * kSlice);
+    const int nrows = r1 - r0;
+    const int c0 = a.blk_cellptr[blk], ncell = a.blk_cellptr[blk + 1] - c0;
+    const int h0 = a.blk_haloptr[blk], nhalo = a.blk_haloptr[blk + 1] - h0;
+
+    // ---- phase 0: stage plan slices, quadrature tables and the fields of the block's vertices ----
+    for (int i = tid; i <= ns; i += T) sp[i] = a.A.ptr[s0 + i];
+    for (int i = tid; i <= nrows; i += T) ip[i] = a.incptr[r0 + i];
+    const int ip0 = a.incptr[r0], ninc = a.incptr[r1] - ip0;
+    for (int i = tid; i < ninc; i += T) ic[i] = a.inccode[ip0 + i];
+    if (tid < a.quad.nq) qk[tid] = QPoint{a.quad.phi0[tid], a.quad.phi1[tid], a.quad.phi2[tid], a.quad.w2[tid]};
+    if (tid >= 64 && tid - 64 < a.qpoly.nq) {
+        const int k = tid - 64;
+        qp[k] = QPoint{a.qpoly.phi0[k], a.qpoly.phi1[k], a.qpoly.phi2[k], a.qpoly.w2[k]};
+    }
+    for (int i = tid; i < nrows + nhalo; i += T) {
+        const int v = i < nrows ? r0 + i : a.blk_halo[h0 + (i - nrows)];   // own rows: consecutive -> coalesced
+        const double2 xy = a.m.xy[v];
+        fld[AF_X * V + i] = xy.x;
+        fld[AF_Y * V + i] = xy.y;
+#pragma unroll
+        for (int k = 0; k < kAsmFields - 2; ++k) fld[(k + 2) * V + i] = a.fld[k][v];
+        bcf[i] = a.bcflag ? a.bcflag[v] : (uint8_t)0;
+    }
+    __syncthreads();
+
+    // ---- phase 1: one thread per cell touching the owned rows; tensors stay in registers until all fields are read ----
+    CellOut out[R];
+    const ushort4* __restrict__ cellv = reinterpret_cast<const ushort4*>(a.blk_cellv) + c0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int t = tid + r * T;
+        if (t < ncell) {
+            const ushort4 cv = cellv[t];
+            cell_tensor<NQ, NP>(a, fld, bcf, qk, qp, V, cv.x, cv.y, cv.z, out[r]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int t = tid + r * T;
+        if (t < ncell) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) et[k * E + t] = out[r].K[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) et[(9 + k) * E + t] = out[r].F[k];
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2a: one thread per SELL slot of the owned slices ----
+    {
+        const int n0 = sp[0], n1 = sp[ns];
+        for (int s = n0 + tid; s < n1; s += T) {
+            int j = 0;
+            while (j + 1 < ns && sp[j + 1] <= s) ++j;
+            const int off = s - sp[j];
+            const int k = off >> 6, lane = off & 63;
+            const int v = (s0 + j) * kSlice + lane;
+            const uint32_t src = a.slotsrc[s];
+            double sum = 0.0;
+            if (k == 0) {
+                if (v < a.A.n_rows) {
+                    const int i = v - r0;
+                    const int kb = ip[i] - ip0, ke = ip[i + 1] - ip0;
+                    for (int q = kb; q < ke; ++q) {  // ascending cell id: fixed summation order
+                        const int code = ic[q];
+                        sum += et[(4 * (code & 3)) * E + (code >> 2)];   // K_ii of that cell: li*3 + li
+                    }
+                }
+            } else {
+                const uint32_t lo = src & 0x3FFFu, hi = (src >> 14) & 0x3FFFu;
+                if ((lo >> 4) != kSrcNone) sum = et[(lo & 15u) * E + (lo >> 4)];
+                if ((hi >> 4) != kSrcNone) sum += et[(hi & 15u) * E + (hi >> 4)];
+            }
+            const uint32_t bc = src >> 28;   // Dirichlet rows and columns zeroed, unit diagonal
+            if (bc) sum = (bc == 2u) ? 1.0 : 0.0;
+            if (k == 0 && v < a.A.n_rows) a.dinv[v] = (sum != 0.0) ? 1.0 / sum : 1.0;  // the diagonal is stored first
+            a.vals[s] = sum;  // padding slots hold exact zeros
+        }
+    }
+    // ---- phase 2b: one thread per owned residual row ----
+    for (int i = tid; i < nrows; i += T) {
+        const int v = r0 + i;
+        double sum = 0.0;
+        const int kb = ip[i] - ip0, ke = ip[i + 1] - ip0;
+        for (int q = kb; q < ke; ++q) {
+            const int code = ic[q];
+            sum += et[(9 + (code & 3)) * E + (code >> 2)];
+        }
+        if (bcf[i]) sum = a.fld[0][v] - a.bc_value;  // set_bc(b, bcs, x, -1): F = N - g
+        a.F[v] = sum;
+    }
+}
+
+// Per-slot Dirichlet code (0 keep, 1 zero, 2 one) into bits 28-29 of the slot's plan word, so that the assembly
+// neither gathers flags per entry nor streams a second per-slot array.
+__global__ __launch_bounds__(kBlock) void k_slot_bc(DevSell A, const uint8_t* __restrict__ flag, uint32_t* __restrict__ slotsrc) {
+    for (int v = blockIdx.x * kBlock + threadIdx.x; v < A.n_rows; v += gridDim.x * kBlock) {
+        const int s = v / kSlice, l = v % kSlice, base = A.ptr[s];
+        const bool bv = flag[v];
+        for (int k = 0; k < (int)A.rowlen[v]; ++k) {
+            const int slot = base + k * kSlice + l;
+            const int u = A.col[slot];
+            const bool bu = flag[u];
+            const uint32_t code = (bv | bu) ? ((u == v && bv) ? 2u : 1u) : 0u;
+            slotsrc[slot] = (slotsrc[slot] & 0x0FFFFFFFu) | (code << 28);
+        }
+    }
+}
+
+void launch_slot_bc(Ctx* c) {
+    const int g = (int)std::min<int64_t>((c->n_own + kBlock - 1) / kBlock, 4096);
+    hipLaunchKernelGGL(k_slot_bc, dim3(g), dim3(kBlock), 0, c->stream, c->sell(), c->d_bcflag, c->d_slotsrc);
+}
+
+static void fill_asm_args(Ctx* c, double dt, AsmArgs& a) {
+    a.m.xy = c->d_xy;
+    a.m.cells = c->d_cells;
+    const int order[kAsmFields - 2] = {SHK_N, SHK_N_N, SHK_B, SHK_QX, SHK_QY, SHK_Z_B, SHK_Z_S, SHK_G, SHK_MELT_N,
+                                       SHK_STORAGE, SHK_INPUTS};
+    for (int k = 0; k < kAsmFields - 2; ++k) a.fld[k] = c->f[order[k]];
+    a.bcflag = c->has_bc ? c->d_bcflag : nullptr;
+    a.slotsrc = c->d_slotsrc;
+    a.bc_value = c->bc_value;
+    a.inv_rwg_dt = 1.0 / (c->dp.rwg * dt);
+    a.A = c->sell();
+    a.blk_slice0 = c->d_blk_slice0; a.blk_cellptr = c->d_blk_cellptr; a.blk_haloptr = c->d_blk_haloptr;
+    a.blk_halo = c->d_blk_halo; a.blk_cellv = c->d_blk_cellv;
+    a.incptr = c->d_incptr; a.inccode = c->d_inccode;
+    a.cells_max = c->plan.cells_max; a.slices_max = c->plan.slices_max; a.verts_max = c->plan.verts_max;
+    a.inc_max = c->plan.max_inc_per_block;
+    a.lds_region_a = (int)c->asm_region_a;
+    a.F = c->d_F; a.vals = c->d_vals; a.dinv = c->d_dinv;
+    a.p = c->dp;
+    a.quad = c->quad;
+    a.qpoly = c->dp.n_is_3 ? c->qpoly5 : c->quad;
+}
+
+// LDS of one assembly workgroup: region A (staged fields, then the element tensors) + tables
+size_t assemble_lds_bytes(const HostPlan& P, size_t* region_a) {
+    const size_t E = P.cells_max, S = P.slices_max, V = P.verts_max;
+    size_t ra = std::max((size_t)kAsmFields * V, 12 * E) * sizeof(double);
+    ra = (ra + 15) & ~size_t(15);
+    if (region_a) *region_a = ra;
+    size_t lds = ra + 2 * kMaxQuad * sizeof(QPoint) + (S + 1) * sizeof(int) + (S * kSlice + 1) * sizeof(int) +
+                 (size_t)P.max_inc_per_block * sizeof(uint16_t) + V;
+    return (lds + 15) & ~size_t(15);
+}
+
+template <int T>
+static void launch_T(Ctx* c, const AsmArgs& a, bool builtin) {
+    if (builtin) launch_phase(c, SHK_PH_ASSEMBLE, k_assemble<T, 15, 7>, dim3(c->nblk), dim3(T), c->asm_lds, a);
+    else launch_phase(c, SHK_PH_ASSEMBLE, k_assemble<T, 0, 0>, dim3(c->nblk), dim3(T), c->asm_lds, a);
+}
+
+void launch_assemble(Ctx* c, double dt) {
+    AsmArgs a;
+    fill_asm_args(c, dt, a);
+    const bool builtin = a.quad.nq == 15 && a.qpoly.nq == 7;
+    if (c->asm_threads == 512) launch_T<512>(c, a, builtin);
+    else launch_T<256>(c, a, builtin);
+}
+
+// Dynamic LDS above 64 KiB has to be requested per kernel.
+hipError_t prepare_kernels(Ctx* c) {
+    const void* fns[] = {reinterpret_cast<const void*>(&k_assemble<256, 15, 7>), reinterpret_cast<const void*>(&k_assemble<256, 0, 0>),
+                         reinterpret_cast<const void*>(&k_assemble<512, 15, 7>), reinterpret_cast<const void*>(&k_assemble<512, 0, 0>)};
+    for (const void* f : fns) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->asm_lds);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+}  // namespace shk

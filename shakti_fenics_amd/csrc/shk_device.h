@@ -256,20 +256,22 @@ __device__ __forceinline__ void fused_restrict(const RestrictArgs& ra, int g, do
     }
 }
 
+constexpr int kAsmCellsMax = 640;   // cells one assembly workgroup stages (PlanOptions::cells_max is capped to it)
 struct AsmArgs {
     Mesh m;
-    const double *N, *N_n, *b, *qx, *qy, *z_b, *z_s, *G, *melt_n, *storage, *inputs;
+    const double* fld[11];   // N, N_n, b, qx, qy, z_b, z_s, G, melt_n, storage, inputs
     const uint8_t* bcflag;   // nullptr if no Dirichlet dofs
-    const uint8_t* slotbc;   // per SELL slot: 0 keep, 1 zero, 2 one (nullptr if no Dirichlet dofs)
-    const uint32_t* slotsrc; // per off-diagonal SELL slot: its (at most two) staged cells, 16 bits each:
-                             // (block-local cell slot << 4) | (3 li + lj), 0xFFFF = none
+    const uint32_t* slotsrc; // per SELL slot: its (at most two) staged cells, 14 bits each ((block-local cell slot << 4)
+                             // | (3 li + lj), cell slot kSrcNone = none) and the slot's Dirichlet code in bits 28-29
     double bc_value;
     double inv_rwg_dt;       // 1 / (rho_w g dt)
     DevSell A;
-    const int32_t *blk_slice0, *blk_cellptr, *blk_cells, *incptr;
-    const uint16_t* inccode;
-    int cells_max;           // LDS stride E
-    int slices_max;
+    const int32_t *blk_slice0, *blk_cellptr, *blk_haloptr, *blk_halo, *incptr;
+    const uint16_t *blk_cellv, *inccode;
+    int cells_max;           // LDS stride E of the element tensors
+    int verts_max;           // LDS stride V of the staged fields
+    int slices_max, inc_max;
+    int lds_region_a;        // bytes of the fields / element-tensor region
     // outputs
     double* F;
     double* vals;
@@ -421,7 +423,7 @@ struct Ctx {
     double* d_io = nullptr;                   // 2*n_loc staging for permuted field I/O
     double* f[SHK_FIELD_COUNT] = {nullptr};   // SHK_Q slot unused (qx/qy are separate)
     double *d_melt_tmp = nullptr, *d_b_tmp = nullptr, *d_m0 = nullptr;
-    uint8_t *d_bcflag = nullptr, *d_slotbc = nullptr;
+    uint8_t* d_bcflag = nullptr;
     uint32_t* d_slotsrc = nullptr;
     bool has_bc = false;
     double bc_value = 0.0;
@@ -429,11 +431,13 @@ struct Ctx {
     uint8_t* d_rowlen = nullptr;
     int32_t *d_cbase = nullptr, *d_ptr16 = nullptr;
     uint16_t* d_col16 = nullptr;
-    int32_t *d_blk_slice0 = nullptr, *d_blk_cellptr = nullptr, *d_blk_cells = nullptr, *d_incptr = nullptr;
-    uint16_t* d_inccode = nullptr;
+    int32_t *d_blk_slice0 = nullptr, *d_blk_cellptr = nullptr, *d_blk_haloptr = nullptr, *d_blk_halo = nullptr,
+            *d_incptr = nullptr;
+    uint16_t *d_inccode = nullptr, *d_blk_cellv = nullptr;
     int nblk = 0;
     int64_t cells_staged = 0;  // cells computed per assembly incl. those shared between blocks
-    size_t asm_lds = 0;
+    size_t asm_lds = 0, asm_region_a = 0;
+    int asm_threads = 256;     // workgroup size of k_assemble (SHK_ASM_THREADS = 256 | 512)
     double *d_F = nullptr, *d_vals = nullptr, *d_vals_s = nullptr, *d_dinv = nullptr;
     float *d_vals32 = nullptr, *d_dinv32 = nullptr;   // float copies read by the multigrid preconditioner
     // Krylov vectors
@@ -483,6 +487,7 @@ int set_error(const std::string& msg);
 
 // launchers (shk_kernels.hip)
 hipError_t prepare_kernels(Ctx* c);
+size_t assemble_lds_bytes(const HostPlan& P, size_t* region_a);
 void launch_assemble(Ctx* c, double dt);
 void launch_slot_bc(Ctx* c);
 void launch_scale(Ctx* c);

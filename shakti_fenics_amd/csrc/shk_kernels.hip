@@ -50,251 +50,6 @@ __device__ __forceinline__ double glen_pow(double N, const DevParams& p) {
     return p.n_is_3 ? N * N : pow(fabs(N), p.n - 1.0);
 }
 
-// ------------------------------------------------------------------ assembly
-// Two quadrature loops per cell.  Only the transmissivity integral  int |b|^3 / (1 + omega |q| / nu)  is not
-// a polynomial: it uses the degree-7 rule (15 points; sqrt + divide per point, nothing else).  Every other term
-// of the residual and of the Jacobian is a polynomial of degree <= 5 in the reference coordinates for Glen's
-// n = 3 (b N^3 phi_i, b N^2 phi_i phi_j, ...), so the 7-point degree-5 rule integrates it exactly -- the same
-// numbers as the degree-7 rule up to round-off, at less than half the work.  For a non-integer n both loops
-// run the degree-7 rule.
-__global__ __launch_bounds__(kBlock) void k_assemble(const AsmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int E = a.cells_max;
-    double* et = reinterpret_cast<double*>(smem);                 // [12][E] element tensors
-    int* sp = reinterpret_cast<int*>(et + 12 * (size_t)E);        // [slices_max+1] SELL ptr of owned slices
-    int* ip = sp + (a.slices_max + 1);                            // [rows+1] incptr of owned rows
-    uint16_t* ic = reinterpret_cast<uint16_t*>(ip + (a.slices_max * kSlice + 1));  // incidence codes
-
-    const int blk = blockIdx.x;
-    const int tid = threadIdx.x;
-    const int s0 = a.blk_slice0[blk], ns = a.blk_slice0[blk + 1] - s0;
-    const int r0 = s0 * kSlice;
-    const int r1 = min(a.A.n_rows, (s0 + ns) * kSlice);
-    const int nrows = r1 - r0;
-    const int c0 = a.blk_cellptr[blk], ncell = a.blk_cellptr[blk + 1] - c0;
-    const DevParams& p = a.p;
-
-    for (int i = tid; i <= ns; i += kBlock) sp[i] = a.A.ptr[s0 + i];
-    for (int i = tid; i <= nrows; i += kBlock) ip[i] = a.incptr[r0 + i];
-    const int ip0 = a.incptr[r0], ninc = a.incptr[r1] - ip0;
-    for (int i = tid; i < ninc; i += kBlock) ic[i] = a.inccode[ip0 + i];
-
-    // ---- phase 1: one thread per cell touching the owned rows ----
-    for (int t = tid; t < ncell; t += kBlock) {
-        const int c = a.blk_cells[c0 + t];
-        const int v0 = a.m.cells[3 * (size_t)c + 0], v1 = a.m.cells[3 * (size_t)c + 1],
-                  v2 = a.m.cells[3 * (size_t)c + 2];
-        const double2 p0 = a.m.xy[v0], p1 = a.m.xy[v1], p2 = a.m.xy[v2];
-        const double d1x = p1.x - p0.x, d1y = p1.y - p0.y, d2x = p2.x - p0.x, d2y = p2.y - p0.y;
-        const double det = d1x * d2y - d1y * d2x;
-        const double inv = 1.0 / det;
-        const double area = 0.5 * fabs(det);
-        const double g1x = d2y * inv, g1y = -d2x * inv, g2x = -d1y * inv, g2y = d1x * inv;
-        const double g0x = -(g1x + g2x), g0y = -(g1y + g2y);
-
-        const double b0 = a.b[v0], b1 = a.b[v1], b2 = a.b[v2];
-        const double qx0 = a.qx[v0], qx1 = a.qx[v1], qx2 = a.qx[v2];
-        const double qy0 = a.qy[v0], qy1 = a.qy[v1], qy2 = a.qy[v2];
-        // WaterFlux with the Reynolds switch, constitutive.py:11-20: q_w = -K grad(h); sK = int K dx
-        double sK = 0.0;
-        for (int k = 0; k < a.quad.nq; ++k) {
-            const double f0 = a.quad.phi0[k], f1 = a.quad.phi1[k], f2 = a.quad.phi2[k];
-            const double bk = b0 * f0 + b1 * f1 + b2 * f2;
-            const double qxk = qx0 * f0 + qx1 * f1 + qx2 * f2;
-            const double qyk = qy0 * f0 + qy1 * f1 + qy2 * f2;
-            const double qn = sqrt(qxk * qxk + qyk * qyk);
-            const double ab = fabs(bk);
-            sK += a.quad.w2[k] * (ab * ab * ab) / (1.0 + p.om_nu * qn);
-        }
-        sK *= area * p.kcoef;
-
-        const double N0 = a.N[v0], N1 = a.N[v1], N2 = a.N[v2];
-        const double m0_ = a.melt_n[v0], m1_ = a.melt_n[v1], m2_ = a.melt_n[v2];
-        // grad(Head), constitutive.py:6-9.  Like FFCx, every coefficient is differenced on its own (reference
-        // gradient = nodal differences f1 - f0, f2 - f0): rounding is then relative to the differences, not to
-        // the head's magnitude (~1e3 m over cells of ~10 m), which puts the floor of ||F|| an order of magnitude
-        // lower than differencing nodal heads would.
-        double dh1, dh2;
-        {
-            const double zb0 = a.z_b[v0], zb1 = a.z_b[v1], zb2 = a.z_b[v2];
-            const double zs0 = a.z_s[v0], zs1 = a.z_s[v1], zs2 = a.z_s[v2];
-            dh1 = head_diff(zb1 - zb0, zs1 - zs0, N1 - N0, p);
-            dh2 = head_diff(zb2 - zb0, zs2 - zs0, N2 - N0, p);
-        }
-        const double ghx = dh1 * g1x + dh2 * g2x, ghy = dh1 * g1y + dh2 * g2y;
-        const double gbx = (b1 - b0) * g1x + (b2 - b0) * g2x, gby = (b1 - b0) * g1y + (b2 - b0) * g2y;
-        const double gmx = (m1_ - m0_) * g1x + (m2_ - m0_) * g2x, gmy = (m1_ - m0_) * g1y + (m2_ - m0_) * g2y;
-        const double gb2 = gbx * gbx + gby * gby;
-        const double inv_den = 1.0 / (1.0 + gb2);
-        const double gmgb = gmx * gbx + gmy * gby;
-        const double Nn0 = a.N_n[v0], Nn1 = a.N_n[v1], Nn2 = a.N_n[v2];
-        const double G0 = a.G[v0], G1 = a.G[v1], G2 = a.G[v2];
-        const double s0 = a.storage[v0], s1 = a.storage[v1], s2 = a.storage[v2];
-        const double i0 = a.inputs[v0], i1 = a.inputs[v1], i2 = a.inputs[v2];
-
-        double F0 = 0.0, F1 = 0.0, F2 = 0.0;
-        double T00 = 0.0, T01 = 0.0, T02 = 0.0, T11 = 0.0, T12 = 0.0, T22 = 0.0;
-        const double qgh0 = p.rwg * (qx0 * ghx + qy0 * ghy), qgh1 = p.rwg * (qx1 * ghx + qy1 * ghy),
-                     qgh2 = p.rwg * (qx2 * ghx + qy2 * ghy);  // rho_w g q.grad(h) is P1: interpolate its nodal values
-        for (int k = 0; k < a.qpoly.nq; ++k) {
-            const double f0 = a.qpoly.phi0[k], f1 = a.qpoly.phi1[k], f2 = a.qpoly.phi2[k];
-            const double w = a.qpoly.w2[k] * area;
-            const double Nk = N0 * f0 + N1 * f1 + N2 * f2;
-            const double Nnk = Nn0 * f0 + Nn1 * f1 + Nn2 * f2;
-            const double bk = b0 * f0 + b1 * f1 + b2 * f2;
-            const double Gk = G0 * f0 + G1 * f1 + G2 * f2;
-            const double mk = m0_ * f0 + m1_ * f1 + m2_ * f2;
-            const double sk = s0 * f0 + s1 * f1 + s2 * f2;
-            const double ik = i0 * f0 + i1 * f1 + i2 * f2;
-            const double qghk = qgh0 * f0 + qgh1 * f1 + qgh2 * f2;
-            // Melt, constitutive.py:22-27 (div of the cell-wise P1 product expanded)
-            const double melt = (Gk - qghk) / p.Lh + (mk * gb2 + bk * gmgb) * inv_den;
-            const double pw = glen_pow(Nk, p);
-            const double closure = p.A * bk * Nk * pw;                 // constitutive.py:29-31
-            const double stor = sk * (Nk - Nnk) * a.inv_rwg_dt;        // solvers.py:42
-            const double ws = w * (p.c_m * melt - closure - stor - ik);
-            F0 += ws * f0; F1 += ws * f1; F2 += ws * f2;
-            const double wd = w * (p.A * p.n * bk * pw + sk * a.inv_rwg_dt);
-            T00 += wd * f0 * f0; T01 += wd * f0 * f1; T02 += wd * f0 * f2;
-            T11 += wd * f1 * f1; T12 += wd * f1 * f2; T22 += wd * f2 * f2;
-        }
-        // flux term: K grad(h).grad(phi_i)
-        double Fe0 = sK * (ghx * g0x + ghy * g0y) + F0;
-        double Fe1 = sK * (ghx * g1x + ghy * g1y) + F1;
-        double Fe2 = sK * (ghx * g2x + ghy * g2y) + F2;
-        const double kk = -sK / p.rwg;
-        const double d00 = g0x * g0x + g0y * g0y, d01 = g0x * g1x + g0y * g1y, d02 = g0x * g2x + g0y * g2y;
-        const double d11 = g1x * g1x + g1y * g1y, d12 = g1x * g2x + g1y * g2y, d22 = g2x * g2x + g2y * g2y;
-        // int phi_i q_x dx = area/12 (sum q_x + q_x,i): exact P1 mass matrix
-        const double cq = p.c_m / p.Lh * area * (1.0 / 12.0);
-        const double sx = qx0 + qx1 + qx2, sy = qy0 + qy1 + qy2;
-        const double Px0 = cq * (sx + qx0), Px1 = cq * (sx + qx1), Px2 = cq * (sx + qx2);
-        const double Py0 = cq * (sy + qy0), Py1 = cq * (sy + qy1), Py2 = cq * (sy + qy2);
-        const double K00 = kk * d00 + (Px0 * g0x + Py0 * g0y) - T00;
-        const double K01 = kk * d01 + (Px0 * g1x + Py0 * g1y) - T01;
-        const double K02 = kk * d02 + (Px0 * g2x + Py0 * g2y) - T02;
-        const double K10 = kk * d01 + (Px1 * g0x + Py1 * g0y) - T01;
-        const double K11 = kk * d11 + (Px1 * g1x + Py1 * g1y) - T11;
-        const double K12 = kk * d12 + (Px1 * g2x + Py1 * g2y) - T12;
-        const double K20 = kk * d02 + (Px2 * g0x + Py2 * g0y) - T02;
-        const double K21 = kk * d12 + (Px2 * g1x + Py2 * g1y) - T12;
-        const double K22 = kk * d22 + (Px2 * g2x + Py2 * g2y) - T22;
-        if (a.bcflag && (a.bcflag[v0] | a.bcflag[v1] | a.bcflag[v2])) {
-            // apply_lifting(alpha=-1): F_i += K_ij (g - N_j) over Dirichlet columns j
-            const double l0 = a.bcflag[v0] ? a.bc_value - N0 : 0.0;
-            const double l1 = a.bcflag[v1] ? a.bc_value - N1 : 0.0;
-            const double l2 = a.bcflag[v2] ? a.bc_value - N2 : 0.0;
-            Fe0 += K00 * l0 + K01 * l1 + K02 * l2;
-            Fe1 += K10 * l0 + K11 * l1 + K12 * l2;
-            Fe2 += K20 * l0 + K21 * l1 + K22 * l2;
-        }
-        et[0 * E + t] = K00; et[1 * E + t] = K01; et[2 * E + t] = K02;
-        et[3 * E + t] = K10; et[4 * E + t] = K11; et[5 * E + t] = K12;
-        et[6 * E + t] = K20; et[7 * E + t] = K21; et[8 * E + t] = K22;
-        et[9 * E + t] = Fe0; et[10 * E + t] = Fe1; et[11 * E + t] = Fe2;
-    }
-    __syncthreads();
-
-    // ---- phase 2a: one thread per SELL slot of the owned slices; the plan names the (at most two) staged
-    //      cells of an off-diagonal entry directly, the diagonal sums its row's incidence list ----
-    {
-        const int n0 = sp[0], n1 = sp[ns];
-        for (int s = n0 + tid; s < n1; s += kBlock) {
-            int j = 0;
-            while (j + 1 < ns && sp[j + 1] <= s) ++j;
-            const int off = s - sp[j];
-            const int k = off >> 6, lane = off & 63;
-            const int v = (s0 + j) * kSlice + lane;
-            double sum = 0.0;
-            if (v < a.A.n_rows && k < (int)a.A.rowlen[v]) {
-                if (k == 0) {
-                    const int i = v - r0;
-                    const int kb = ip[i] - ip0, ke = ip[i + 1] - ip0;
-                    for (int q = kb; q < ke; ++q) {  // ascending cell id: fixed summation order
-                        const int code = ic[q];
-                        sum += et[(4 * (code & 3)) * E + (code >> 2)];   // K_ii of that cell: li*3 + li
-                    }
-                } else {
-                    const uint32_t src = a.slotsrc[s];
-                    const uint32_t lo = src & 0xFFFFu, hi = src >> 16;
-                    sum = et[(lo & 15u) * E + (lo >> 4)];
-                    if (hi != 0xFFFFu) sum += et[(hi & 15u) * E + (hi >> 4)];
-                }
-                if (a.slotbc) {  // Dirichlet rows and columns zeroed, unit diagonal
-                    const int bc = a.slotbc[s];
-                    if (bc) sum = (bc == 2) ? 1.0 : 0.0;
-                }
-                if (k == 0) a.dinv[v] = (sum != 0.0) ? 1.0 / sum : 1.0;  // the diagonal is stored first
-            }
-            a.vals[s] = sum;  // padding slots hold exact zeros
-        }
-    }
-    // ---- phase 2b: one thread per owned residual row ----
-    for (int i = tid; i < nrows; i += kBlock) {
-        const int v = r0 + i;
-        double sum = 0.0;
-        const int kb = ip[i] - ip0, ke = ip[i + 1] - ip0;
-        for (int q = kb; q < ke; ++q) {
-            const int code = ic[q];
-            sum += et[(9 + (code & 3)) * E + (code >> 2)];
-        }
-        if (a.bcflag && a.bcflag[v]) sum = a.N[v] - a.bc_value;  // set_bc(b, bcs, x, -1)
-        a.F[v] = sum;
-    }
-}
-
-// Per-slot Dirichlet code (0 keep, 1 zero, 2 one) so that the assembly does not gather flags per entry.
-__global__ __launch_bounds__(kBlock) void k_slot_bc(DevSell A, const uint8_t* __restrict__ flag, uint8_t* __restrict__ out) {
-    for (int v = blockIdx.x * kBlock + threadIdx.x; v < A.n_rows; v += gridDim.x * kBlock) {
-        const int s = v / kSlice, l = v % kSlice, base = A.ptr[s];
-        const bool bv = flag[v];
-        for (int k = 0; k < (int)A.rowlen[v]; ++k) {
-            const int slot = base + k * kSlice + l;
-            const int u = A.col[slot];
-            const bool bu = flag[u];
-            out[slot] = (bv | bu) ? ((u == v && bv) ? 2 : 1) : 0;
-        }
-    }
-}
-
-void launch_slot_bc(Ctx* c) {
-    const int g = (int)std::min<int64_t>((c->n_own + kBlock - 1) / kBlock, 4096);
-    hipLaunchKernelGGL(k_slot_bc, dim3(g), dim3(kBlock), 0, c->stream, c->sell(), c->d_bcflag, c->d_slotbc);
-}
-
-static void fill_asm_args(Ctx* c, double dt, AsmArgs& a) {
-    a.m.xy = c->d_xy;
-    a.m.cells = c->d_cells;
-    a.N = c->f[SHK_N]; a.N_n = c->f[SHK_N_N]; a.b = c->f[SHK_B]; a.qx = c->f[SHK_QX]; a.qy = c->f[SHK_QY];
-    a.z_b = c->f[SHK_Z_B]; a.z_s = c->f[SHK_Z_S]; a.G = c->f[SHK_G]; a.melt_n = c->f[SHK_MELT_N];
-    a.storage = c->f[SHK_STORAGE]; a.inputs = c->f[SHK_INPUTS];
-    a.bcflag = c->has_bc ? c->d_bcflag : nullptr;
-    a.slotbc = c->has_bc ? c->d_slotbc : nullptr;
-    a.slotsrc = c->d_slotsrc;
-    a.bc_value = c->bc_value;
-    a.inv_rwg_dt = 1.0 / (c->dp.rwg * dt);
-    a.A = c->sell();
-    a.blk_slice0 = c->d_blk_slice0; a.blk_cellptr = c->d_blk_cellptr; a.blk_cells = c->d_blk_cells;
-    a.incptr = c->d_incptr; a.inccode = c->d_inccode;
-    a.cells_max = c->plan.cells_max; a.slices_max = c->plan.slices_max;
-    a.F = c->d_F; a.vals = c->d_vals; a.dinv = c->d_dinv;
-    a.p = c->dp;
-    a.quad = c->quad;
-    a.qpoly = c->dp.n_is_3 ? c->qpoly5 : c->quad;
-}
-
-void launch_assemble(Ctx* c, double dt) {
-    AsmArgs a;
-    fill_asm_args(c, dt, a);
-    launch_phase(c, SHK_PH_ASSEMBLE, k_assemble, dim3(c->nblk), dim3(kBlock), c->asm_lds, a);
-}
-
-// Dynamic LDS above 64 KiB has to be requested per kernel.
-hipError_t prepare_kernels(Ctx* c) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->asm_lds);
-}
-
 // A' = A D^-1 (right Jacobi preconditioning folded into the matrix once per Newton iteration)
 __global__ __launch_bounds__(kBlock) void k_scale(int64_t slots, const int32_t* __restrict__ col,
                                                   const double* __restrict__ vals,

@@ -217,8 +217,13 @@ std::string build_plan(int64_t n_own, int64_t n_loc, int64_t ne, const double* x
 
     // ---- assembly blocks: runs of slices whose incident cells fit the LDS budget ----
     P.slices_max = std::max(1, opt.slices_max);
-    P.cells_max = std::min(opt.cells_max, 4095);   // slotsrc keeps the cell slot in 12 bits
-    P.slotsrc.assign((size_t)A.slots, 0xFFFFFFFFu);
+    P.cells_max = std::min(opt.cells_max, (int)kSrcNone - 1);   // slotsrc keeps the cell slot in 10 bits
+    P.slotsrc.assign((size_t)A.slots, kSrcEmpty);
+    P.blk_haloptr.assign(1, 0);
+    P.blk_halo.clear();
+    P.blk_cellv.clear();
+    P.verts_max = 0;
+    std::vector<int32_t> hlocal(n_loc, -1);
     std::vector<int32_t> mark(ne, -1), slot(ne, 0);
     P.blk_slice0.assign(1, 0);
     P.blk_cellptr.assign(1, 0);
@@ -237,6 +242,29 @@ std::string build_plan(int64_t n_own, int64_t n_loc, int64_t ne, const double* x
             }
         std::sort(P.blk_cells.begin() + c0, P.blk_cells.end());
         for (size_t i = c0; i < P.blk_cells.size(); ++i) slot[P.blk_cells[i]] = (int32_t)(i - c0);
+        // halo vertices of the block (ascending ids) and the cells' local vertex ids
+        {
+            const size_t h0 = P.blk_halo.size();
+            for (size_t i = c0; i < P.blk_cells.size(); ++i)
+                for (int k = 0; k < 3; ++k) {
+                    const int32_t u = cells[3 * (int64_t)P.blk_cells[i] + k];
+                    if ((u < ra || u >= rb) && hlocal[u] < 0) { hlocal[u] = 0; P.blk_halo.push_back(u); }
+                }
+            std::sort(P.blk_halo.begin() + h0, P.blk_halo.end());
+            const int32_t nrows = (int32_t)(rb - ra);
+            for (size_t i = h0; i < P.blk_halo.size(); ++i) hlocal[P.blk_halo[i]] = nrows + (int32_t)(i - h0);
+            if (nrows + (int64_t)(P.blk_halo.size() - h0) > 65535) plan_error = "an assembly block touches more than 65535 vertices";
+            for (size_t i = c0; i < P.blk_cells.size(); ++i) {
+                for (int k = 0; k < 3; ++k) {
+                    const int32_t u = cells[3 * (int64_t)P.blk_cells[i] + k];
+                    P.blk_cellv.push_back((uint16_t)((u >= ra && u < rb) ? u - ra : hlocal[u]));
+                }
+                P.blk_cellv.push_back(0);
+            }
+            P.verts_max = std::max(P.verts_max, nrows + (int)(P.blk_halo.size() - h0));
+            for (size_t i = h0; i < P.blk_halo.size(); ++i) hlocal[P.blk_halo[i]] = -1;
+            P.blk_haloptr.push_back((int32_t)P.blk_halo.size());
+        }
         int inc = 0;
         for (int64_t v = ra; v < rb; ++v)
             for (int32_t k = v2c_ptr[v]; k < v2c_ptr[v + 1]; ++k) {
@@ -251,7 +279,7 @@ std::string build_plan(int64_t n_own, int64_t n_loc, int64_t ne, const double* x
             const int32_t sl = (int32_t)(v / kSlice), ln = (int32_t)(v % kSlice), base = A.ptr[sl];
             for (int k = 1; k < A.rowlen[v]; ++k) {
                 const int32_t slot_id = base + k * kSlice + ln, u = A.col[slot_id];
-                uint32_t code[2] = {0xFFFFu, 0xFFFFu};
+                uint32_t code[2] = {kSrcNone << 4, kSrcNone << 4};
                 int nsrc = 0;
                 for (int32_t q = v2c_ptr[v]; q < v2c_ptr[v + 1]; ++q) {
                     const int32_t c = v2c[q];
@@ -263,7 +291,7 @@ std::string build_plan(int64_t n_own, int64_t n_loc, int64_t ne, const double* x
                     ++nsrc;
                 }
                 if (nsrc < 1 || nsrc > 2) { plan_error = "an edge belongs to more than two cells (non-manifold mesh)"; }
-                P.slotsrc[slot_id] = code[0] | (code[1] << 16);
+                P.slotsrc[slot_id] = code[0] | (code[1] << 14);
             }
         }
         P.max_inc_per_block = std::max(P.max_inc_per_block, inc);

@@ -17,6 +17,8 @@
 namespace shk {
 
 constexpr int kSlice = 64;  // rows per SELL slice = wavefront width
+constexpr uint32_t kSrcNone = 0x3FFu;      // slotsrc: cell slot meaning "no source"
+constexpr uint32_t kSrcEmpty = (kSrcNone << 4) | (kSrcNone << 18);   // a slot without sources, Dirichlet code 0
 
 struct PlanOptions {
     int slices_max = 4;    // slices (of 64 rows) owned by one assembly block
@@ -87,9 +89,17 @@ struct HostPlan {
     std::vector<int32_t> blk_cells;    // cell ids, ascending inside a block
     std::vector<int32_t> incptr;       // n_own+1 into inccode
     std::vector<uint16_t> inccode;     // (block-local cell slot << 2) | local vertex index
-    std::vector<uint32_t> slotsrc;     // per SELL slot: the <= 2 staged cells of an off-diagonal entry, 16 bits each:
-                                       // (cell slot << 4) | (3 li + lj); 0xFFFF = none (diagonal / padding: unused)
+    std::vector<uint32_t> slotsrc;     // per SELL slot: the <= 2 staged cells of an off-diagonal entry, 14 bits each
+                                       // (bits 0-13 and 14-27): (cell slot << 4) | (3 li + lj); cell slot kSrcNone = none
+                                       // (diagonal / padding).  Bits 28-29 are the slot's Dirichlet code, written on
+                                       // the device by shk_set_dirichlet (0 keep, 1 zero, 2 one).
     int max_inc_per_block = 0;
+    // staging of the nodal fields: a block's vertices are its owned rows (local ids 0 .. rows-1, loaded coalesced)
+    // followed by its halo vertices (the other vertices of its cells, gathered)
+    std::vector<int32_t> blk_haloptr;  // nblk+1 into blk_halo
+    std::vector<int32_t> blk_halo;     // internal vertex ids, ascending inside a block
+    std::vector<uint16_t> blk_cellv;   // 4 per staged cell: local ids of its three vertices, 0
+    int verts_max = 0;                 // largest rows + halo of a block (LDS stride of the staged fields)
 };
 
 // xy: (n_loc,2) external order; cells: (ne,3) external local ids, every cell must touch at least one
