@@ -360,9 +360,54 @@ __global__ __launch_bounds__(kBlock) void k_power_init(int32_t n, int32_t n_cols
     }
 }
 
+// Gershgorin bound of the spectrum of D^-1 A: max_i sum_j |a_ij| |1 / a_ii| (one partial maximum per workgroup)
+__global__ __launch_bounds__(kBlock) void k_gershgorin(const DevSell A, const float* __restrict__ vals,
+                                                       const float* __restrict__ dinv, double* __restrict__ part) {
+    __shared__ double sh[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double m = 0.0;
+    for (int s = blockIdx.x * 4 + wave; s < A.nslice; s += gridDim.x * 4) {
+        const int base = A.ptr[s], width = (A.ptr[s + 1] - base) >> 6, row = s * kSlice + lane;
+        float sum = 0.0f;
+        for (int k = 0; k < width; ++k) sum += fabsf(vals[base + k * kSlice + lane]);   // padding slots hold zeros
+        if (row < A.n_rows) m = fmax(m, (double)(sum * fabsf(dinv[row])));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_down(m, o, 64));
+    if (lane == 0) sh[wave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+}
+
 static int small_grid(int64_t n) { return (int)std::min<int64_t>(1024, std::max<int64_t>(1, (n + kBlock - 1) / kBlock)); }
 
 static DevSell level_sell(const Ctx* c, const AmgHierarchy& H, size_t l);
+
+// Largest common factor <= 1 of a sweep sequence's dampings w_k = f c_k / lambda such that the sequence's error
+// polynomial  prod_k (1 - w_k t)  stays within [-1, 1] at t = G, the Gershgorin bound of the spectrum: beyond the
+// last root 1 / w_k the polynomial grows monotonically, so |p(G)| <= 1 means no eigenmode in (1 / w_max, G] is
+// amplified (between the roots |p| < 1 for the damping ratios used here).  This is what keeps the cycle off the
+// cliff measured at 10M rows: dampings 20 % above the tuned ones amplify the top of the spectrum by 1.6 per cycle
+// and BiCGStab needs 585 iterations instead of 47; 30 % above, it diverges.
+static double cap_factor(const double* cs, int n, double lambda, double G) {
+    if (!(G > 0.0) || !(lambda > 0.0)) return 1.0;
+    auto amp = [&](double f) {
+        double p = 1.0;
+        for (int k = 0; k < n; ++k) p *= (1.0 - f * cs[k] / lambda * G);
+        return std::fabs(p);
+    };
+    // amp(0) = 1 and amp < 1 just above 0: the first factor (scanning upwards) at which it exceeds 1 again bounds
+    // the safe range, which is therefore contiguous from 0
+    constexpr int steps = 4000;
+    for (int i = 1; i <= steps; ++i)
+        if (amp((double)i / steps) > 1.0) return (double)(i - 1) / steps;
+    return 1.0;
+}
+static void damping_caps(AmgHierarchy& H) {
+    const double c2s[2] = {H.c1, H.c2};
+    H.cap2 = cap_factor(c2s, 2, H.lambda, H.gersh);
+    H.cap4 = cap_factor(H.c4, 4, H.lambda, H.gersh);
+}
 
 // Largest eigenvalue of D^-1 A over the levels that run as separate launches (the one-workgroup tail levels
 // are coarser Galerkin products of the same operator), by `steps` power iterations each; one host sync.
@@ -371,8 +416,24 @@ static hipError_t estimate_lambda(Ctx* c, AmgHierarchy& H) {
     // 2.37 / 2.54 at 10M rows where 16 give 2.07 -- but a mesh-independent measure (2.04 .. 2.07 from 12k to 10M rows)
     // that the dampings H.c1, H.c2, H.c4 were tuned against.
     constexpr int steps = 16;
-    double lam = 0.0;
+    double lam = 0.0, gersh = 0.0;
     std::vector<double> h(2 * (size_t)kMaxParts);
+    // Gershgorin bound G >= lambda_max(D^-1 A) over every sparse level: the dampings are capped so that no sweep
+    // sequence amplifies anything in (0, G] (damping_caps below) -- a guarantee that does not depend on how well the
+    // power iteration has converged
+    for (size_t l = 0; l < H.xf.size(); ++l) {
+        const DevSell A = level_sell(c, H, l);
+        const int grid = std::min((A.nslice + 3) / 4, 1024);
+        hipLaunchKernelGGL(k_gershgorin, dim3(grid), dim3(kBlock), 0, c->stream, A, l == 0 ? H.top_vals : H.lv[l].vals,
+                           l == 0 ? H.top_dinv : H.lv[l].dinv, c->d_part + (size_t)P_AUX * kMaxParts);
+        hipError_t e = hipMemcpyAsync(h.data(), c->d_part + (size_t)P_AUX * kMaxParts, (size_t)grid * sizeof(double),
+                                      hipMemcpyDeviceToHost, c->stream);
+        if (e != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return e;
+        for (int b = 0; b < grid; ++b) if (std::isfinite(h[b])) gersh = std::max(gersh, h[b]);
+        if ((e = hipMemsetAsync(c->d_part + (size_t)P_AUX * kMaxParts, 0, (size_t)grid * sizeof(double), c->stream)) != hipSuccess)
+            return e;
+    }
     for (size_t l = 0; l < H.xf.size(); ++l) {
         if (l > 0 && H.lv[l].n <= 4096) break;
         const DevSell A = level_sell(c, H, l);
@@ -412,19 +473,24 @@ static hipError_t estimate_lambda(Ctx* c, AmgHierarchy& H) {
     // subdomains must agree on the damping: take the largest estimate
     if (c->comm.kind != Comm::NONE && c->comm.nranks > 1) {
         const int R = c->comm.nranks;
-        std::vector<double> buf((size_t)R, 0.0);
+        std::vector<double> buf((size_t)2 * R, 0.0);
         buf[c->comm.rank] = lam;
+        buf[R + c->comm.rank] = gersh;
         double* d = c->d_part + (size_t)P_AUX * kMaxParts;
-        hipError_t e = hipMemcpyAsync(d, buf.data(), R * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        hipError_t e = hipMemcpyAsync(d, buf.data(), 2 * R * sizeof(double), hipMemcpyHostToDevice, c->stream);
         if (e != hipSuccess) return e;
-        if ((e = allreduce_buffer(c, d, d, (size_t)R)) != hipSuccess) return e;
-        if ((e = hipMemcpyAsync(buf.data(), d, R * sizeof(double), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return e;
+        if ((e = allreduce_buffer(c, d, d, (size_t)2 * R)) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(buf.data(), d, 2 * R * sizeof(double), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return e;
         if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return e;
-        for (double v : buf) lam = std::max(lam, v);
-        if ((e = hipMemsetAsync(d, 0, R * sizeof(double), c->stream)) != hipSuccess) return e;
+        for (int r = 0; r < R; ++r) { lam = std::max(lam, buf[r]); gersh = std::max(gersh, buf[R + r]); }
+        if ((e = hipMemsetAsync(d, 0, 2 * R * sizeof(double), c->stream)) != hipSuccess) return e;
     }
     H.lambda = lam > 0.0 ? 1.1 * lam : 2.0 / 0.7;   // no estimate: fall back to w = 0.7 ... 
-    if (getenv("SHK_DEBUG")) fprintf(stderr, "[shk] multigrid smoother: lambda_max(D^-1 A) ~ %.4f\n", lam);
+    H.gersh = gersh;
+    damping_caps(H);
+    if (getenv("SHK_DEBUG"))
+        fprintf(stderr, "[shk] multigrid smoother: 16-step power estimate %.4f, Gershgorin bound %.4f, damping caps %.3f (2 sweeps) "
+                        "%.3f (4 sweeps)\n", lam, gersh, H.cap2, H.cap4);
     return hipSuccess;
 }
 
@@ -576,7 +642,8 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
     const int* done = &c->d_state->done;
     static const double fw1 = getenv("SHK_AMG_W1") ? atof(getenv("SHK_AMG_W1")) : 0.0;   // experiment overrides
     static const double fw2 = getenv("SHK_AMG_W2") ? atof(getenv("SHK_AMG_W2")) : 0.0;
-    const float w1 = (float)(fw1 > 0.0 ? fw1 : H.c1 / H.lambda), w2 = (float)(fw2 > 0.0 ? fw2 : H.c2 / H.lambda);
+    const float w1 = (float)(fw1 > 0.0 ? fw1 : H.cap2 * H.c1 / H.lambda), w2 = (float)(fw2 > 0.0 ? fw2 : H.cap2 * H.c2 / H.lambda);
+    const double l4 = H.lambda / H.cap4;   // the four-sweep sequences divide their c4[k] by this
     const float alpha = (float)H.alpha;
     hipError_t e;
     const size_t lt = H.rep ? nx : tail_start(H);   // a replicated coarse part takes over after the last launch level
@@ -675,8 +742,8 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
             // A replicated hierarchy's top level is a coarse level of the whole cycle: four sweeps, like its peers.
             const float w2_fine = w2;
             const bool four = H.top_four && H.coarse4;
-            const float omega = four ? (float)(H.c4[0] / H.lambda) : w1;
-            const float w2 = four ? (float)(H.c4[1] / H.lambda) : w2_fine;
+            const float omega = four ? (float)(H.c4[0] / l4) : w1;
+            const float w2 = four ? (float)(H.c4[1] / l4) : w2_fine;
             if (fused) {
                 AmgFirstArgs<double> f{DevSell{X.n_fine, X.n_coarse_cols, X.ap_nslice, sell_fits_cache(X.ap_slots, kAmgSlotBytes),
                                                X.ap_ptr, X.ap_col, X.ap_rowlen, X.ap_cbase, X.ap_ptr16, X.ap_col16},
@@ -694,8 +761,8 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
             if (halo && (e = halo_exchange_plan_f32(c, *HP, H.x0)) != hipSuccess) return e;
             launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)H.x0, zout, w2, done);
             if (four) {
-                launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)zout, H.x0, (float)(H.c4[2] / H.lambda), done);
-                launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)H.x0, zout, (float)(H.c4[3] / H.lambda), done);
+                launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)zout, H.x0, (float)(H.c4[2] / l4), done);
+                launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)H.x0, zout, (float)(H.c4[3] / l4), done);
             }
         } else {
             const AmgLevel& L = H.lv[l];
@@ -705,8 +772,8 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
             // operator) -- rehearsed with 4 subdomains at 1M rows: 57 -> 54 iterations per Newton iteration with
             // two exchanging levels, 51 -> 38 with all (one subdomain: 40), at no extra message.
             const bool more = H.coarse4;
-            const float lw1 = more ? (float)(H.c4[0] / H.lambda) : w1;
-            const float lw2 = more ? (float)(H.c4[1] / H.lambda) : w2;
+            const float lw1 = more ? (float)(H.c4[0] / l4) : w1;
+            const float lw2 = more ? (float)(H.c4[1] / l4) : w2;
             if (fused) {
                 AmgFirstArgs<float> f{DevSell{X.n_fine, X.n_coarse_cols, X.ap_nslice, sell_fits_cache(X.ap_slots, kAmgSlotBytes),
                                               X.ap_ptr, X.ap_col, X.ap_rowlen, X.ap_cbase, X.ap_ptr16, X.ap_col16},
@@ -738,8 +805,8 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
             PhaseTimer t(c, SHK_PH_AMG_COARSE);
             launch_post<false>(c, A, L.vals, L.dinv, (const float*)L.r, (const float*)L.x, L.x2, lw2, done);
             if (more) {
-                launch_post<false>(c, A, L.vals, L.dinv, (const float*)L.r, (const float*)L.x2, L.x, (float)(H.c4[2] / H.lambda), done);
-                launch_post<false>(c, A, L.vals, L.dinv, (const float*)L.r, (const float*)L.x, L.x2, (float)(H.c4[3] / H.lambda), done);
+                launch_post<false>(c, A, L.vals, L.dinv, (const float*)L.r, (const float*)L.x2, L.x, (float)(H.c4[2] / l4), done);
+                launch_post<false>(c, A, L.vals, L.dinv, (const float*)L.r, (const float*)L.x, L.x2, (float)(H.c4[3] / l4), done);
             }
         }
     }

@@ -342,6 +342,8 @@ struct AmgHierarchy {
     // below).  c = (2.35, 1.41) is the pair measured best on the 10M-row system (lambda there = 2.35: w = 1.0,
     // 0.6; 61 iterations per Newton step against 69 for 0.7, 0.7 -- and 0.9, 0.9 diverges).  (SHK_AMG_W1/W2)
     double lambda = 0.0;             // 0: not estimated yet
+    double gersh = 0.0;              // Gershgorin bound of lambda_max(D^-1 A) over the levels (rigorous, unlike lambda)
+    double cap2 = 1.0, cap4 = 1.0;   // factors <= 1 on the two- / four-sweep dampings: no amplification on (0, gersh]
     double c1 = 2.35, c2 = 1.25;     // w = (1.03, 0.55) on the synthetic meshes.  Iterations per Newton iteration at 10M |
                                      // 1M rows with the final cycle: (1.03, 0.62) 45.1 | 40.9, (1.03, 0.55) 44.8 | 39.8,
                                      // (0.95, 0.55) 46.0 | 41.2, (0.85, 0.50) 48.0 | 40.9 -- and (1.03, 0.70) 97.6 | 41.9: the
