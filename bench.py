@@ -6,9 +6,16 @@ synthetic rectangular ice-sheet mesh of BASELINE.json / SURVEY.md section 8(d).
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
 
 A "step" is one time step of the solve loop (`/root/reference/source/solvers.py:168-229`): Newton
-solve for N (fused P1 assembly + Jacobi-BiCGStab per Newton iteration) followed by the fused
-flux / melt / gap-height updates.  value = Nv * (Newton iterations in the timed steps) / wall time.
-Rank 0 prints ONE JSON line.
+solve for N (fused P1 assembly + one BiCGStab solve per Newton iteration, right-preconditioned by the
+aggregation multigrid of DESIGN.md 4b; `--precond jacobi` selects north_star's Jacobi, which diverges at
+10M DOF) followed by the fused flux / melt / gap-height updates.
+value = Nv * (Newton iterations in the timed steps) / wall time.  Rank 0 prints ONE JSON line.
+
+After the timed region (never inside it): one profiled step for the roofline legs; the steady-state march
+of configurations C2 / C4 (until ||dN|| / ||N|| < 1e-8 or 50 steps, reporting which); the CPU
+baselines of BASELINE.md section 2 (oracle LU and oracle Jacobi-BiCGStab, C1 and a bounded sample).
+With several ranks the halo / reduction transport is RCCL; if it cannot be used the run FAILS (exit code != 0)
+unless --allow-host-staged is given, and the line's "transport" field says which one ran.
 """
 from __future__ import annotations
 
@@ -44,45 +51,101 @@ def parse():
     ap.add_argument("--cpu-sample", default="560x112", help="nx x ny of the CPU-baseline sample mesh (same geometry)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--transport", default="rccl", help="rccl (xGMI) | gloo (host-staged, tests)")
+    ap.add_argument("--allow-host-staged", action="store_true",
+                    help="if RCCL cannot be used, run the same solver over the host-staged gloo transport instead of failing")
+    ap.add_argument("--steady-max", type=int, default=50, help="N=1: total steps of the steady-state march after the timed "
+                    "region (0: skip); stops early once ||dN||/||N|| < 1e-8")
     ap.add_argument("--precond", default="amg", help="amg (aggregation multigrid, default) | jacobi (north_star's solver; diverges at 10M DOF)")
     ap.add_argument("--amg-steps", type=int, default=2, help="extra steps timed with the multigrid preconditioner (N=1)")
     ap.add_argument("--quiet", action="store_true")
     return ap.parse_args()
 
 
-def cpu_baseline(args) -> dict:
-    """The oracle in the reference's algorithmic configuration (P1 assembly, 15-point quadrature,
-    exact sparse LU per Newton iteration, DOLFINx Newton defaults), one thread, on a bounded sample
-    of the same geometry.  This is the only place bench.py touches oracle/."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+def _oracle_case(dom, storage, moulins):
     import shakti_oracle as O
-    from shakti_fenics_amd.mesh import rectangle_mesh
-    from shakti_fenics_amd.synthetic import CONFIGS, N_BDRY, outflow_predicate, synthetic_fields
-
-    nx, ny = (int(v) for v in args.cpu_sample.split("x"))
-    _, _, Lx, Ly = CONFIGS[args.config]
-    dom = rectangle_mesh(nx, ny, Lx, Ly, order=args.order)
-    sf = synthetic_fields(dom, storage_on=bool(args.storage), moulins=0)
+    from shakti_fenics_amd.synthetic import outflow_predicate, synthetic_fields
+    sf = synthetic_fields(dom, storage_on=storage, moulins=moulins)
     nv = dom.num_vertices
     f = O.Fields(N=sf["N_init"].copy(), N_n=sf["N_init"].copy(), b=np.abs(sf["b_init"]), q=sf["q_init"].copy(),
                  melt_n=np.zeros(nv), z_b=sf["z_b"], z_s=sf["z_s"], G=sf["G"], storage=sf["lake_bdry"],
                  inputs=sf["inputs"])
-    bc = O.boundary_dofs(dom.xy, dom.cells, outflow_predicate(dom))
+    return f, O.boundary_dofs(dom.xy, dom.cells, outflow_predicate(dom))
+
+
+def _oracle_leg(dom, storage, steps, dt, linear, budget_s=60.0):
+    """`steps` time steps of the oracle; returns DOF-updates/s with its split into assembly and linear solve."""
+    import shakti_oracle as O
+    from shakti_fenics_amd.synthetic import N_BDRY
+    f, bc = _oracle_case(dom, storage, 0)
+    nv = dom.num_vertices
     prm = O.Params()
     last, _ = O.last_cell_of_vertex(nv, dom.cells)
-    steps = 5   # ~12-15 s of single-thread work on the GPU box's host
+    its = kits = done = 0
     t0 = time.perf_counter()
-    its = 0
     for i in range(steps):
-        dt = 0.1 * args.dt if i == 0 else args.dt
-        n, conv, _ = O.newton_solve(dom.xy, dom.cells, f, dt, prm, bc, N_BDRY, linear="lu")
+        n, conv, info = O.newton_solve(dom.xy, dom.cells, f, 0.1 * dt if i == 0 else dt, prm, bc, N_BDRY, linear=linear,
+                                       krylov_rtol=1e-10)
+        if not conv:
+            break
+        O.update_explicit(dom.xy, dom.cells, f, 0.1 * dt if i == 0 else dt, prm, last)
         its += n
-        O.update_explicit(dom.xy, dom.cells, f, dt, prm, last)
+        kits += sum(info["krylov_its"])
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
     wall = time.perf_counter() - t0
-    return dict(value=nv * its / wall, unit="DOF-updates/s", cores=1, kind="port",
-                sample=f"oracle (NumPy assembly + SciPy SuperLU, reference configuration) on a {nx}x{ny} = {nv}-DOF "
-                       f"mesh of the same {Lx/1e3:.0f}x{Ly/1e3:.0f} km geometry, {steps} steps, {its} Newton "
-                       f"iterations, {wall:.1f} s on 1 of {os.cpu_count()} host cores")
+    return dict(value=nv * its / wall if wall > 0 else 0.0, unit="DOF-updates/s", dofs=nv, steps=done, newton_its=its,
+                krylov_its_per_newton=(kits / its if its and linear != "lu" else None), seconds=wall,
+                linear="SciPy SuperLU (the reference's ksp preonly + pc lu)" if linear == "lu"
+                else "Jacobi-BiCGStab, SciPy CSR SpMV, rtol 1e-10 (the GPU path's north_star solver)")
+
+
+def cpu_baseline(args) -> dict:
+    """BASELINE.md section 2 on the box's host cores, one thread each (NumPy assembly; SuperLU and SciPy's CSR product are
+    single-threaded).  Headline = the oracle in the reference's algorithmic configuration (P1 assembly, 15-point
+    quadrature, exact sparse LU per Newton iteration, DOLFINx Newton defaults) on a bounded sample of the bench
+    geometry; `legs` add the same algorithm on C1 (5 041 and 12 321 DOF, 10 steps) and the CPU twin of the Jacobi-
+    BiCGStab solver on C1 (at 62k DOF it already needs ~1900 iterations per Newton iteration and minutes per step).  This is the only place bench.py touches oracle/."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from shakti_fenics_amd.mesh import rectangle_mesh
+    from shakti_fenics_amd.synthetic import CONFIGS, config_mesh
+
+    nx, ny = (int(v) for v in args.cpu_sample.split("x"))
+    _, _, Lx, Ly = CONFIGS[args.config]
+    sample = rectangle_mesh(nx, ny, Lx, Ly, order=args.order)
+    head = _oracle_leg(sample, bool(args.storage), 5, args.dt, "lu")
+    legs = {"sample_lu": head}
+    legs["c1_5k_lu"] = _oracle_leg(config_mesh("c1_5k"), True, 10, args.dt, "lu", 20.0)
+    legs["c1_12k_lu"] = _oracle_leg(config_mesh("c1_12k"), True, 10, args.dt, "lu", 20.0)
+    legs["c1_5k_bicgstab"] = _oracle_leg(config_mesh("c1_5k"), True, 10, args.dt, "bicgstab", 20.0)
+    legs["c1_12k_bicgstab"] = _oracle_leg(config_mesh("c1_12k"), True, 10, args.dt, "bicgstab", 20.0)
+    return dict(value=head["value"], unit="DOF-updates/s", cores=1, kind="port",
+                sample=f"oracle (NumPy assembly + SciPy SuperLU, reference configuration) on a {nx}x{ny} = {head['dofs']}-DOF "
+                       f"mesh of the same {Lx/1e3:.0f}x{Ly/1e3:.0f} km geometry, {head['steps']} steps, {head['newton_its']} Newton "
+                       f"iterations, {head['seconds']:.1f} s on 1 of {os.cpu_count()} host cores",
+                legs=legs,
+                published_reference="2.32e5 DOF-timesteps/s on 8 MPI ranks of an unstated CPU, real-data setup "
+                                    "(/root/reference/notebooks/example.ipynb:54-55): different hardware, setup and unit")
+
+
+def steady_march(run, args, say) -> dict:
+    """march (storage off) until ||N_k - N_(k-1)|| / ||N_k|| < 1e-8 or 50 steps in all, and
+    say which ended it.  Outside the timed region; fields cross PCIe once per step for the norm."""
+    tol = 1e-8
+    prev = run.ctx.get_field("N")
+    drift = None
+    while run.next_step < args.steady_max:
+        run.step()
+        cur = run.ctx.get_field("N")
+        drift = float(np.linalg.norm(cur - prev) / np.linalg.norm(cur))
+        prev = cur
+        if drift < tol:
+            break
+    reached = drift is not None and drift < tol
+    say(f"steady-state march: {run.next_step} steps, drift {drift}")
+    return dict(rule=f"||dN||/||N|| < {tol:g} or {args.steady_max} steps", steps_run=run.next_step, drift_last_step=drift,
+                ended_by="tolerance" if reached else "step limit",
+                note=None if args.storage == 0 else "storage on: a transient configuration, the march is informative only")
 
 
 def main():
@@ -147,6 +210,7 @@ def main():
         "value": nv * newton / wall if newton else 0.0,
         "unit": "DOF-updates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "transport": getattr(run, "transport", "none") if world > 1 else "none (one GPU)",
         "ms_per_step": 1e3 * wall / max(args.steps, 1),
         "higher_is_better": True,
         "scaling": "strong",
@@ -159,14 +223,26 @@ def main():
             "newton_its": newton, "krylov_its": krylov,
             "krylov_its_per_newton": krylov / max(newton, 1),
             "krylov": f"BiCGStab, right preconditioner {args.precond}, true-residual rtol {args.krylov_rtol:g}",
+            "first_step": "0.1 dt (solvers.py:81); |b_init| instead of the reference's signed draw (DESIGN.md section 1)",
             "parallelism": f"dd{world}" if world > 1 else "single",
         },
     }
+    if world > 1:
+        st = run.ctx.comm_stats()
+        nk = max(krylov, 1)
+        out["message_rounds"] = {"rank": 0, "ghost_exchanges_per_krylov_it": st["exchanges"] / nk,
+                                 "allreduces_per_krylov_it": st["allreduces"] / nk,
+                                 "bytes_exchanged_per_krylov_it": st["bytes_exchanged"] / nk,
+                                 "bytes_allreduced_per_krylov_it": st["bytes_allreduced"] / nk,
+                                 "note": "all rounds of rank 0 since context creation (setup, warm-up and timed steps) over the "
+                                         "timed steps' Krylov iterations: an upper bound of the per-iteration figure"}
     if not args.no_roofline:
         roof = run.roofline(HBM_PEAK_GBS)  # one more (collective) step with per-launch hipEvents
         if rank == 0:
             out["roofline"] = roof
         say("roofline step done")
+    if world == 1 and args.steady_max > 0 and args.precond != "jacobi":
+        out["steady_state"] = steady_march(run, args, say)
     if world == 1 and args.precond == "jacobi" and args.amg_steps > 0:
         # same state, same metric, with the multigrid preconditioner of DESIGN.md section 9
         run.set_precond("amg")
@@ -182,7 +258,7 @@ def main():
         out["multigrid"] = {"value": nv * nn / w, "unit": "DOF-updates/s", "steps": args.amg_steps,
                             "ms_per_step": 1e3 * w / args.amg_steps, "newton_its": nn, "krylov_its": kk,
                             "krylov_its_per_newton": kk / max(nn, 1),
-                            "note": "same workload continued with precond=amg (aggregation multigrid V(1,1)); "
+                            "note": "same workload continued with precond=amg (aggregation multigrid V(0,2), DESIGN.md 4b); "
                                     "not the headline: north_star names Jacobi-BiCGStab"}
         say(f"multigrid leg done: {nn} newton, {kk} krylov, {w:.2f} s")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -129,6 +129,9 @@ typedef int (*shk_exchange_fn)(void* user, int32_t n_nbr, const int32_t* nbr, co
 typedef int (*shk_allreduce_fn)(void* user, double* buf, int64_t n);
 int shk_comm_init_callbacks(shk_ctx* ctx, int32_t rank, int32_t nranks, shk_exchange_fn exchange,
                             shk_allreduce_fn allreduce, void* user);
+/* Message rounds this context has issued since creation: n[0] ghost exchanges, n[1] all-reduces, n[2] bytes sent in
+ * exchanges, n[3] bytes all-reduced (per rank).  Differences around a solve give rounds per Krylov iteration. */
+int shk_comm_stats(shk_ctx* ctx, int64_t n[4]);
 /* Refresh the ghost entries of a field from their owners (scatter_forward, solvers.py:197,229). */
 int shk_halo_update(shk_ctx* ctx, int32_t field);
 

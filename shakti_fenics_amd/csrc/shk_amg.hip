@@ -360,6 +360,80 @@ __global__ __launch_bounds__(kBlock) void k_power_init(int32_t n, int32_t n_cols
     }
 }
 
+// ---- Lanczos estimate of lambda_max(D^-1 A) in the |D| inner product (D^-1 A is self-adjoint in it when A is
+// symmetric; the Jacobian's advection-like part is a small perturbation).  Three kernels per step:
+//   k_lanczos_w   w = D^-1 A v - beta v_prev,  partial (w, v)_D
+//   k_lanczos_n   w -= alpha v,                partial (w, w)_D
+//   k_lanczos_s   v_next = w / beta   (written over v_prev)
+__global__ __launch_bounds__(kBlock) void k_lanczos_w(const DevSell A, const float* __restrict__ vals,
+                                                      const float* __restrict__ dinv, const float* __restrict__ v,
+                                                      const float* __restrict__ vprev, float beta, float* __restrict__ w,
+                                                      double* __restrict__ part) {
+    __shared__ double sh[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double acc = 0.0;
+    for (SliceLoop it(A, wave_index()); it.valid(); it.next()) {
+        const float sum = sell_row_sum(A, it.m, vals, v, lane);
+        const int row = it.s * kSlice + lane;
+        if (row < A.n_rows) {
+            const float di = dinv[row];
+            const float wi = di * sum - beta * vprev[row];
+            w[row] = wi;
+            acc += (double)wi * v[row] / fabs((double)di);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (lane == 0) sh[wave] = acc;
+    __syncthreads();
+    if (tid == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ __launch_bounds__(kBlock) void k_lanczos_n(int32_t n, float alpha, const float* __restrict__ v,
+                                                      const float* __restrict__ dinv, float* __restrict__ w,
+                                                      double* __restrict__ part) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    for (int32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const float wi = w[i] - alpha * v[i];
+        w[i] = wi;
+        acc += (double)wi * wi / fabs((double)dinv[i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ __launch_bounds__(kBlock) void k_lanczos_s(int32_t n, float inv_beta, const float* __restrict__ w, float* __restrict__ vnext) {
+    for (int32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) vnext[i] = w[i] * inv_beta;
+}
+
+// Largest eigenvalue of the symmetric tridiagonal (alpha, beta) by bisection on the Sturm count.
+static double tridiag_lambda_max(const std::vector<double>& al, const std::vector<double>& be) {
+    const int m = (int)al.size();
+    double lo = al[0], hi = al[0];
+    for (int i = 0; i < m; ++i) {
+        const double r = (i > 0 ? std::fabs(be[i - 1]) : 0.0) + (i + 1 < m ? std::fabs(be[i]) : 0.0);
+        lo = std::min(lo, al[i] - r);
+        hi = std::max(hi, al[i] + r);
+    }
+    auto count_below = [&](double x) {   // eigenvalues < x
+        int cnt = 0;
+        double d = 1.0;
+        for (int i = 0; i < m; ++i) {
+            const double b2 = i > 0 ? be[i - 1] * be[i - 1] : 0.0;
+            d = (al[i] - x) - (i > 0 ? b2 / (d == 0.0 ? 1e-300 : d) : 0.0);
+            if (d < 0.0) ++cnt;
+        }
+        return cnt;
+    };
+    for (int it = 0; it < 100; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        if (count_below(mid) >= m) hi = mid; else lo = mid;
+    }
+    return 0.5 * (lo + hi);
+}
+
 // Gershgorin bound of the spectrum of D^-1 A: max_i sum_j |a_ij| |1 / a_ii| (one partial maximum per workgroup)
 __global__ __launch_bounds__(kBlock) void k_gershgorin(const DevSell A, const float* __restrict__ vals,
                                                        const float* __restrict__ dinv, double* __restrict__ part) {
@@ -384,9 +458,10 @@ static int small_grid(int64_t n) { return (int)std::min<int64_t>(1024, std::max<
 static DevSell level_sell(const Ctx* c, const AmgHierarchy& H, size_t l);
 
 // Largest common factor <= 1 of a sweep sequence's dampings w_k = f c_k / lambda such that the sequence's error
-// polynomial  prod_k (1 - w_k t)  stays within [-1, 1] at t = G, the Gershgorin bound of the spectrum: beyond the
-// last root 1 / w_k the polynomial grows monotonically, so |p(G)| <= 1 means no eigenmode in (1 / w_max, G] is
-// amplified (between the roots |p| < 1 for the damping ratios used here).  This is what keeps the cycle off the
+// polynomial  prod_k (1 - w_k t)  stays within [-1, 1] at t = G, an upper bound of the spectrum of D^-1 A (the
+// Lanczos estimate + 5 %, capped by Gershgorin's bound -- which alone is 45 % too pessimistic on these operators:
+// 3.76 against 2.6): beyond the last root 1 / w_k the polynomial grows monotonically, so |p(G)| <= 1 means no
+// eigenmode in (1 / w_max, G] is amplified (between the roots |p| < 1 for the damping ratios used here).  This is what keeps the cycle off the
 // cliff measured at 10M rows: dampings 20 % above the tuned ones amplify the top of the spectrum by 1.6 per cycle
 // and BiCGStab needs 585 iterations instead of 47; 30 % above, it diverges.
 static double cap_factor(const double* cs, int n, double lambda, double G) {
@@ -405,8 +480,63 @@ static double cap_factor(const double* cs, int n, double lambda, double G) {
 }
 static void damping_caps(AmgHierarchy& H) {
     const double c2s[2] = {H.c1, H.c2};
-    H.cap2 = cap_factor(c2s, 2, H.lambda, H.gersh);
-    H.cap4 = cap_factor(H.c4, 4, H.lambda, H.gersh);
+    H.cap2 = cap_factor(c2s, 2, H.lambda, H.lam_max);
+    H.cap4 = cap_factor(H.c4, 4, H.lambda, H.lam_max);
+}
+
+// `steps` Lanczos steps on one level (owned block; ghost columns read as zero); v0, v1, w: scratch vectors of the
+// level.  Returns the largest Ritz value (a lower bound that is within a few per cent after ~30 steps, where 64 power
+// steps are still 5-10 % low on these operators), or 0 on breakdown.
+static hipError_t lanczos_lambda(Ctx* c, const DevSell& A, const float* vals, const float* dinv, float* v0, float* v1,
+                                 float* w, int steps, double* out) {
+    *out = 0.0;
+    const int n = A.n_rows, grid = std::min((A.nslice + 3) / 4, 2048), vgrid = small_grid(n);
+    double* part = c->d_part + (size_t)P_AUX * kMaxParts;
+    std::vector<double> h((size_t)std::max(grid, vgrid));
+    hipError_t e;
+    auto host_sum = [&](int cnt, double* sum) -> hipError_t {
+        hipError_t e2 = hipMemcpyAsync(h.data(), part, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (e2 != hipSuccess) return e2;
+        if ((e2 = hipStreamSynchronize(c->stream)) != hipSuccess) return e2;
+        double a = 0.0;
+        for (int i = 0; i < cnt; ++i) a += h[i];
+        *sum = a;
+        return hipSuccess;
+    };
+    const dim3 g1(std::min(1024, (A.n_cols + kBlock - 1) / kBlock));
+    hipLaunchKernelGGL(k_power_init, g1, dim3(kBlock), 0, c->stream, n, A.n_cols, v1);          // start vector
+    if ((e = hipMemsetAsync(v0, 0, (size_t)A.n_cols * sizeof(float), c->stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(w, 0, (size_t)A.n_cols * sizeof(float), c->stream)) != hipSuccess) return e;
+    // normalise v1 in the D norm: reuse k_lanczos_n with alpha = 0 on a copy in w
+    if ((e = hipMemcpyAsync(w, v1, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, c->stream)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_lanczos_n, dim3(vgrid), dim3(kBlock), 0, c->stream, n, 0.0f, (const float*)v1, dinv, w, part);
+    double nn = 0.0;
+    if ((e = host_sum(vgrid, &nn)) != hipSuccess) return e;
+    if (!(nn > 0.0) || !std::isfinite(nn)) return hipSuccess;
+    hipLaunchKernelGGL(k_lanczos_s, dim3(vgrid), dim3(kBlock), 0, c->stream, n, (float)(1.0 / std::sqrt(nn)), (const float*)w, v1);
+    std::vector<double> al, be;
+    float* vprev = v0;
+    float* v = v1;
+    double beta = 0.0;
+    for (int j = 0; j < steps; ++j) {
+        hipLaunchKernelGGL(k_lanczos_w, dim3(grid), dim3(kBlock), 0, c->stream, A, vals, dinv, (const float*)v,
+                           (const float*)vprev, (float)beta, w, part);
+        double a = 0.0, b2 = 0.0;
+        if ((e = host_sum(grid, &a)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_lanczos_n, dim3(vgrid), dim3(kBlock), 0, c->stream, n, (float)a, (const float*)v, dinv, w, part);
+        if ((e = host_sum(vgrid, &b2)) != hipSuccess) return e;
+        if (!std::isfinite(a) || !std::isfinite(b2)) break;
+        al.push_back(a);
+        beta = std::sqrt(std::max(b2, 0.0));
+        if (!(beta > 1e-6 * std::fabs(a)) || j + 1 == steps) break;   // invariant subspace found / done
+        be.push_back(beta);
+        hipLaunchKernelGGL(k_lanczos_s, dim3(vgrid), dim3(kBlock), 0, c->stream, n, (float)(1.0 / beta), (const float*)w, vprev);
+        std::swap(v, vprev);   // v_next was written over v_prev
+    }
+    if (al.empty()) return hipSuccess;
+    be.resize(al.size() - 1);
+    *out = tridiag_lambda_max(al, be);
+    return hipMemsetAsync(part, 0, (size_t)std::max(grid, vgrid) * sizeof(double), c->stream);
 }
 
 // Largest eigenvalue of D^-1 A over the levels that run as separate launches (the one-workgroup tail levels
@@ -416,7 +546,8 @@ static hipError_t estimate_lambda(Ctx* c, AmgHierarchy& H) {
     // 2.37 / 2.54 at 10M rows where 16 give 2.07 -- but a mesh-independent measure (2.04 .. 2.07 from 12k to 10M rows)
     // that the dampings H.c1, H.c2, H.c4 were tuned against.
     constexpr int steps = 16;
-    double lam = 0.0, gersh = 0.0;
+    static const int kLanczosSteps = getenv("SHK_AMG_LANCZOS") ? atoi(getenv("SHK_AMG_LANCZOS")) : 32;
+    double lam = 0.0, gersh = 0.0, lanczos = 0.0;
     std::vector<double> h(2 * (size_t)kMaxParts);
     // Gershgorin bound G >= lambda_max(D^-1 A) over every sparse level: the dampings are capped so that no sweep
     // sequence amplifies anything in (0, G] (damping_caps below) -- a guarantee that does not depend on how well the
@@ -464,6 +595,14 @@ static hipError_t estimate_lambda(Ctx* c, AmgHierarchy& H) {
         double so = 0.0, sx = 0.0;
         for (int b = 0; b < grid; ++b) { so += h[b]; sx += h[kMaxParts + b]; }
         if (sx > 0.0 && std::isfinite(so)) lam = std::max(lam, std::sqrt(so / sx));
+        {   // converged estimate for the damping caps (the power value above only scales the tuned constants)
+            double ll = 0.0;
+            float* third = l == 0 ? H.x2 : H.lv[l].r;
+            if (third && (e = lanczos_lambda(c, A, vals, dinv, l == 0 ? H.x0 : H.lv[l].x, l == 0 ? H.x1 : H.lv[l].x2, third,
+                                             kLanczosSteps, &ll)) != hipSuccess)
+                return e;
+            lanczos = std::max(lanczos, ll);
+        }
         // (the scratch vectors' ghost columns are still zero, and every V-cycle overwrites their owned rows first)
         // The two partial arrays go back to zero: a replicated global level can have more row groups than this
         // subdomain's own grid, and entries beyond that grid must stay zero for the reductions across subdomains.
@@ -473,24 +612,31 @@ static hipError_t estimate_lambda(Ctx* c, AmgHierarchy& H) {
     // subdomains must agree on the damping: take the largest estimate
     if (c->comm.kind != Comm::NONE && c->comm.nranks > 1) {
         const int R = c->comm.nranks;
-        std::vector<double> buf((size_t)2 * R, 0.0);
+        std::vector<double> buf((size_t)3 * R, 0.0);
         buf[c->comm.rank] = lam;
         buf[R + c->comm.rank] = gersh;
+        buf[2 * R + c->comm.rank] = lanczos;
         double* d = c->d_part + (size_t)P_AUX * kMaxParts;
-        hipError_t e = hipMemcpyAsync(d, buf.data(), 2 * R * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        hipError_t e = hipMemcpyAsync(d, buf.data(), 3 * R * sizeof(double), hipMemcpyHostToDevice, c->stream);
         if (e != hipSuccess) return e;
-        if ((e = allreduce_buffer(c, d, d, (size_t)2 * R)) != hipSuccess) return e;
-        if ((e = hipMemcpyAsync(buf.data(), d, 2 * R * sizeof(double), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return e;
+        if ((e = allreduce_buffer(c, d, d, (size_t)3 * R)) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(buf.data(), d, 3 * R * sizeof(double), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return e;
         if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return e;
-        for (int r = 0; r < R; ++r) { lam = std::max(lam, buf[r]); gersh = std::max(gersh, buf[R + r]); }
-        if ((e = hipMemsetAsync(d, 0, 2 * R * sizeof(double), c->stream)) != hipSuccess) return e;
+        for (int r = 0; r < R; ++r) {
+            lam = std::max(lam, buf[r]);
+            gersh = std::max(gersh, buf[R + r]);
+            lanczos = std::max(lanczos, buf[2 * R + r]);
+        }
+        if ((e = hipMemsetAsync(d, 0, 3 * R * sizeof(double), c->stream)) != hipSuccess) return e;
     }
     H.lambda = lam > 0.0 ? 1.1 * lam : 2.0 / 0.7;   // no estimate: fall back to w = 0.7 ... 
     H.gersh = gersh;
+    // spectral bound the caps use: the Lanczos value + 5 % (it converges from below), never above Gershgorin's
+    H.lam_max = lanczos > 0.0 ? std::min(gersh > 0.0 ? gersh : 1e300, 1.05 * lanczos) : gersh;
     damping_caps(H);
     if (getenv("SHK_DEBUG"))
-        fprintf(stderr, "[shk] multigrid smoother: 16-step power estimate %.4f, Gershgorin bound %.4f, damping caps %.3f (2 sweeps) "
-                        "%.3f (4 sweeps)\n", lam, gersh, H.cap2, H.cap4);
+        fprintf(stderr, "[shk] multigrid smoother: 16-step power estimate %.4f, Lanczos(%d) %.4f, Gershgorin bound %.4f, "
+                        "damping caps %.3f (2 sweeps) %.3f (4 sweeps)\n", lam, kLanczosSteps, lanczos, gersh, H.cap2, H.cap4);
     return hipSuccess;
 }
 

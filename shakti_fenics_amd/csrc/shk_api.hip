@@ -228,6 +228,8 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
     }
     if ((e = dev_alloc(c, &H.x0, (size_t)n_loc0)) != hipSuccess) return e;
     if ((e = dev_alloc(c, &H.x1, (size_t)n_loc0)) != hipSuccess) return e;
+    if ((e = dev_alloc(c, &H.x2, (size_t)n_loc0)) != hipSuccess) return e;
+    if ((e = hipMemset(H.x2, 0, (size_t)n_loc0 * sizeof(float))) != hipSuccess) return e;
     if ((e = hipMemset(H.x1, 0, (size_t)n_loc0 * sizeof(float))) != hipSuccess) return e;
     return hipMemset(H.x0, 0, (size_t)n_loc0 * sizeof(float));
 }
@@ -280,6 +282,7 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
     if (const char* s = getenv("SHK_ASM_SLICES")) opt.slices_max = std::max(1, atoi(s));
     if (const char* s = getenv("SHK_ASM_CELLS")) opt.cells_max = std::max(64, atoi(s));
     opt.cells_max = std::min(opt.cells_max, kAsmCellsMax);
+    opt.slots_max = kAsmSlotsMax;
     if (const char* s = getenv("SHK_ASM_THREADS")) c->asm_threads = atoi(s) == 512 ? 512 : 256;
     if (const char* s = getenv("SHK_SORT_WINDOW")) opt.sort_window = std::max(64, atoi(s));
     if (const char* s = getenv("SHK_REORDER")) opt.reorder = atoi(s) != 0;
@@ -294,6 +297,7 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
     c->cells_staged = (int64_t)P.blk_cells.size();
     c->grid = (int)std::min<int64_t>(kMaxParts, std::max<int64_t>(1, (c->n_own + kBlock - 1) / kBlock));
     c->np = c->grid;
+    if (P.verts_max > kAsmVertsMax) { delete c; return fail("an assembly block touches more than 768 vertices (degenerate mesh?)"); }
     c->asm_lds = assemble_lds_bytes(P, &c->asm_region_a);
     if (c->asm_lds > 160 * 1024) { delete c; return fail("assembly LDS budget exceeds 160 KiB"); }
     auto bail = [&](hipError_t e, const char* what) {
@@ -583,7 +587,7 @@ static int krylov_inner(Ctx* c, const double* rhs, int max_it, KrylovState* out)
 }
 
 static int read_aux_norm(Ctx* c, double* out) {  // fixed-order host sum of the (reduced) P_AUX partials
-    HIPCHK(hipMemcpyAsync(c->h_part, c->d_red + P_AUX * kMaxParts, (size_t)c->np * sizeof(double),
+    HIPCHK(hipMemcpyAsync(c->h_part, c->d_red + (size_t)P_AUX * c->red_stride, (size_t)c->np * sizeof(double),
                           hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     double s = 0.0;
@@ -785,10 +789,11 @@ static int comm_common(Ctx* c, int rank, int nranks) {
         if (r < 0 || r >= nranks || r == rank) return fail("halo plan names a neighbour outside the communicator");
     if (nranks > 1 && c->d_red == c->d_part) {
         double* red = nullptr;
-        if (dev_alloc(c, &red, (size_t)P_COUNT * kMaxParts) != hipSuccess) return fail("alloc reduced partials");
-        HIPCHK(hipMemset(red, 0, (size_t)P_COUNT * kMaxParts * sizeof(double)));
+        if (dev_alloc(c, &red, (size_t)P_COUNT) != hipSuccess) return fail("alloc reduced scalars");
+        HIPCHK(hipMemset(red, 0, (size_t)P_COUNT * sizeof(double)));
         c->d_red = red;
-        c->np = kMaxParts;  // every subdomain reduces the same zero-padded arrays
+        c->np = 1;           // every subdomain reads the same all-reduced scalars
+        c->red_stride = 1;
     }
     c->comm.rank = rank;
     c->comm.nranks = nranks;
@@ -825,6 +830,14 @@ int shk_comm_init_callbacks(shk_ctx* ctx, int32_t rank, int32_t nranks, shk_exch
     c->comm.cb_allreduce = allreduce;
     c->comm.cb_user = user;
     c->comm.kind = Comm::CALLBACK;
+    return 0;
+}
+
+int shk_comm_stats(shk_ctx* ctx, int64_t n[4]) {
+    CHECK_CTX(ctx);
+    if (!n) return fail("null output");
+    const Comm& m = reinterpret_cast<Ctx*>(ctx)->comm;
+    n[0] = m.n_exchange; n[1] = m.n_allreduce; n[2] = m.bytes_exchange; n[3] = m.bytes_allreduce;
     return 0;
 }
 

@@ -216,6 +216,17 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
     const int h0 = a.blk_haloptr[blk], nhalo = a.blk_haloptr[blk + 1] - h0;
 
     // ---- phase 0: stage plan slices, quadrature tables and the fields of the block's vertices ----
+    // the plan words of this thread's slots (phase 2) are requested first: they arrive while phase 1 computes
+    constexpr int kSlotIt = (kAsmSlotsMax + T - 1) / T;
+    uint32_t srcw[kSlotIt];
+    {
+        const int n0 = a.A.ptr[s0], n1 = a.A.ptr[s0 + ns];
+#pragma unroll
+        for (int r = 0; r < kSlotIt; ++r) {
+            const int s = n0 + tid + r * T;
+            srcw[r] = s < n1 ? a.slotsrc[s] : kSrcEmpty;
+        }
+    }
     for (int i = tid; i <= ns; i += T) sp[i] = a.A.ptr[s0 + i];
     for (int i = tid; i <= nrows; i += T) ip[i] = a.incptr[r0 + i];
     const int ip0 = a.incptr[r0], ninc = a.incptr[r1] - ip0;
@@ -225,14 +236,34 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
         const int k = tid - 64;
         qp[k] = QPoint{a.qpoly.phi0[k], a.qpoly.phi1[k], a.qpoly.phi2[k], a.qpoly.w2[k]};
     }
-    for (int i = tid; i < nrows + nhalo; i += T) {
-        const int v = i < nrows ? r0 + i : a.blk_halo[h0 + (i - nrows)];   // own rows: consecutive -> coalesced
-        const double2 xy = a.m.xy[v];
-        fld[AF_X * V + i] = xy.x;
-        fld[AF_Y * V + i] = xy.y;
+    // (all global loads of a thread -- its own row and up to kHaloPer halo vertices -- are issued before the first LDS
+    //  write, so their latencies overlap instead of adding up)
+    {
+        constexpr int kStage = (kAsmVertsMax + T - 1) / T;
+        double sv[kStage][kAsmFields];
+        uint8_t sb[kStage];
 #pragma unroll
-        for (int k = 0; k < kAsmFields - 2; ++k) fld[(k + 2) * V + i] = a.fld[k][v];
-        bcf[i] = a.bcflag ? a.bcflag[v] : (uint8_t)0;
+        for (int r = 0; r < kStage; ++r) {
+            const int i = tid + r * T;
+            if (i < nrows + nhalo && !(a.ablate & 4)) {
+                const int v = i < nrows ? r0 + i : a.blk_halo[h0 + (i - nrows)];   // own rows: consecutive -> coalesced
+                const double2 xy = a.m.xy[v];
+                sv[r][0] = xy.x;
+                sv[r][1] = xy.y;
+#pragma unroll
+                for (int k = 0; k < kAsmFields - 2; ++k) sv[r][k + 2] = a.fld[k][v];
+                sb[r] = a.bcflag ? a.bcflag[v] : (uint8_t)0;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < kStage; ++r) {
+            const int i = tid + r * T;
+            if (i < nrows + nhalo) {
+#pragma unroll
+                for (int k = 0; k < kAsmFields; ++k) fld[k * V + i] = (a.ablate & 4) ? 1.0 + 0.001 * k + 1e-5 * i : sv[r][k];
+                bcf[i] = (a.ablate & 4) ? (uint8_t)0 : sb[r];
+            }
+        }
     }
     __syncthreads();
 
@@ -244,7 +275,14 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
         const int t = tid + r * T;
         if (t < ncell) {
             const ushort4 cv = cellv[t];
-            cell_tensor<NQ, NP>(a, fld, bcf, qk, qp, V, cv.x, cv.y, cv.z, out[r]);
+            if (a.ablate & 1) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) out[r].K[k] = fld[cv.x] + k;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) out[r].F[k] = fld[cv.y] + fld[cv.z];
+            } else {
+                cell_tensor<NQ, NP>(a, fld, bcf, qk, qp, V, cv.x, cv.y, cv.z, out[r]);
+            }
         }
     }
     __syncthreads();
@@ -261,15 +299,18 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
     __syncthreads();
 
     // ---- phase 2a: one thread per SELL slot of the owned slices ----
-    {
+    if (!(a.ablate & 2)) {
         const int n0 = sp[0], n1 = sp[ns];
-        for (int s = n0 + tid; s < n1; s += T) {
+#pragma unroll
+        for (int r = 0; r < kSlotIt; ++r) {
+            const int s = n0 + tid + r * T;
+            if (s >= n1) break;
             int j = 0;
             while (j + 1 < ns && sp[j + 1] <= s) ++j;
             const int off = s - sp[j];
             const int k = off >> 6, lane = off & 63;
             const int v = (s0 + j) * kSlice + lane;
-            const uint32_t src = a.slotsrc[s];
+            const uint32_t src = srcw[r];
             double sum = 0.0;
             if (k == 0) {
                 if (v < a.A.n_rows) {
@@ -343,6 +384,8 @@ static void fill_asm_args(Ctx* c, double dt, AsmArgs& a) {
     a.cells_max = c->plan.cells_max; a.slices_max = c->plan.slices_max; a.verts_max = c->plan.verts_max;
     a.inc_max = c->plan.max_inc_per_block;
     a.lds_region_a = (int)c->asm_region_a;
+    static const int ablate = getenv("SHK_ASM_ABLATE") ? atoi(getenv("SHK_ASM_ABLATE")) : 0;   // timing experiments only
+    a.ablate = ablate;
     a.F = c->d_F; a.vals = c->d_vals; a.dinv = c->d_dinv;
     a.p = c->dp;
     a.quad = c->quad;

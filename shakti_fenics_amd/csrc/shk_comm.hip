@@ -31,6 +31,7 @@ struct RcclApi {
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;   // optional
 };
 
 static RcclApi g_rccl;
@@ -53,6 +54,7 @@ const char* rccl_load() {
     SYM(AllReduce, "ncclAllReduce");
     SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
+    g_rccl.CommGetAsyncError = reinterpret_cast<decltype(g_rccl.CommGetAsyncError)>(dlsym(h, "ncclCommGetAsyncError"));
     g_rccl.h = h;
     return nullptr;
 }
@@ -101,6 +103,8 @@ __global__ __launch_bounds__(kBlock) void k_unpack_f32(int64_t n, const double* 
 static hipError_t exchange_packed(Ctx* c, const HaloPlan& P, double* recv) {
     Comm& m = c->comm;
     const int64_t nsend = P.send_ptr.back(), nrecv = P.recv_ptr.back();
+    m.n_exchange += 1;
+    m.bytes_exchange += nsend * (int64_t)sizeof(double);
     if (m.kind == Comm::RCCL) {
         ncclComm_t comm = reinterpret_cast<ncclComm_t>(m.nccl);
         g_rccl.GroupStart();
@@ -110,6 +114,10 @@ static hipError_t exchange_packed(Ctx* c, const HaloPlan& P, double* recv) {
             if (nr > 0) g_rccl.Recv(recv + P.recv_ptr[k], (size_t)nr, ncclDouble, P.nbr[k], comm, c->stream);
         }
         ncclResult_t r = g_rccl.GroupEnd();
+        if (r == ncclSuccess && g_rccl.CommGetAsyncError) {   // a transport failure must not surface later as a hung solve
+            ncclResult_t ae = ncclSuccess;
+            if (g_rccl.CommGetAsyncError(comm, &ae) != ncclSuccess || (ae != ncclSuccess && ae != ncclInProgress)) r = ncclSystemError;
+        }
         return r == ncclSuccess ? hipSuccess : hipErrorUnknown;
     }
     // CALLBACK: host-staged
@@ -173,6 +181,8 @@ hipError_t allreduce_buffer(Ctx* c, const double* src, double* dst, size_t n) {
         return hipSuccess;
     }
     PhaseTimer t(c, SHK_PH_HALO);
+    m.n_allreduce += 1;
+    m.bytes_allreduce += (int64_t)(n * sizeof(double));
     if (m.kind == Comm::RCCL) {
         ncclResult_t r = g_rccl.AllReduce(src, dst, n, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(m.nccl), c->stream);
         return r == ncclSuccess ? hipSuccess : hipErrorUnknown;
@@ -191,12 +201,27 @@ hipError_t allreduce_buffer(Ctx* c, const double* src, double* dst, size_t n) {
     return hipMemcpyAsync(dst, m.h_red, n * sizeof(double), hipMemcpyHostToDevice, c->stream);
 }
 
-// Element-wise sum over subdomains of `nslots` consecutive partial arrays starting at slot `first`
-// (out of place: the local partials keep zeros beyond this rank's grid, the sums go to d_red).
+// One workgroup per reduction slot: this subdomain's partial array summed in a fixed order.
+__global__ __launch_bounds__(kBlock) void k_reduce_parts(int n, const double* __restrict__ part, double* __restrict__ out) {
+    __shared__ double sh[4];
+    const double* p = part + (size_t)blockIdx.x * kMaxParts;
+    double a = 0.0;
+    for (int i = threadIdx.x; i < n; i += kBlock) a += p[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// Sum over subdomains of `nslots` consecutive reduction slots starting at slot `first`: each subdomain first sums its
+// own partial arrays (fixed order), then ONE all-reduce of nslots doubles (16-32 B) completes them; every subdomain
+// ends up with the same bits, so all take identical decisions.
 hipError_t allreduce_parts(Ctx* c, int first, int nslots) {
     if (c->comm.kind == Comm::NONE || c->comm.nranks <= 1) return hipSuccess;
-    return allreduce_buffer(c, c->d_part + (size_t)first * kMaxParts, c->d_red + (size_t)first * kMaxParts,
-                            (size_t)nslots * kMaxParts);
+    hipLaunchKernelGGL(k_reduce_parts, dim3(nslots), dim3(kBlock), 0, c->stream, c->grid,
+                       c->d_part + (size_t)first * kMaxParts, c->d_red + first);
+    return allreduce_buffer(c, c->d_red + first, c->d_red + first, (size_t)nslots);
 }
 
 }  // namespace shk

@@ -257,6 +257,8 @@ __device__ __forceinline__ void fused_restrict(const RestrictArgs& ra, int g, do
 }
 
 constexpr int kAsmCellsMax = 640;   // cells one assembly workgroup stages (PlanOptions::cells_max is capped to it)
+constexpr int kAsmVertsMax = 768;   // vertices (own rows + halo) one assembly workgroup stages
+constexpr int kAsmSlotsMax = 4096;  // SELL slots of one assembly workgroup (4 slices x 64 rows x mean width <= 16)
 struct AsmArgs {
     Mesh m;
     const double* fld[11];   // N, N_n, b, qx, qy, z_b, z_s, G, melt_n, storage, inputs
@@ -272,6 +274,7 @@ struct AsmArgs {
     int verts_max;           // LDS stride V of the staged fields
     int slices_max, inc_max;
     int lds_region_a;        // bytes of the fields / element-tensor region
+    int ablate;              // timing experiments: 1 skip the element computation, 2 the slot phase, 4 the field loads
     // outputs
     double* F;
     double* vals;
@@ -343,6 +346,7 @@ struct AmgHierarchy {
     // 0.6; 61 iterations per Newton step against 69 for 0.7, 0.7 -- and 0.9, 0.9 diverges).  (SHK_AMG_W1/W2)
     double lambda = 0.0;             // 0: not estimated yet
     double gersh = 0.0;              // Gershgorin bound of lambda_max(D^-1 A) over the levels (rigorous, unlike lambda)
+    double lam_max = 0.0;            // spectral bound the caps use: min(gersh, 1.05 x Lanczos estimate)
     double cap2 = 1.0, cap4 = 1.0;   // factors <= 1 on the two- / four-sweep dampings: no amplification on (0, gersh]
     double c1 = 2.35, c2 = 1.25;     // w = (1.03, 0.55) on the synthetic meshes.  Iterations per Newton iteration at 10M |
                                      // 1M rows with the final cycle: (1.03, 0.62) 45.1 | 40.9, (1.03, 0.55) 44.8 | 39.8,
@@ -357,7 +361,7 @@ struct AmgHierarchy {
     double c4[4] = {1.143, 3.640, 1.430, 2.219};
     int64_t ap_nnz0 = 0;             // stored entries of the finest level's A*P operator
     int32_t n_glob = 0, offset = 0;  // dense coarsest operator: n_glob x n_glob, my rows start at `offset`
-    float *x0 = nullptr, *x1 = nullptr, *cr = nullptr, *cx = nullptr;   // x1: power-iteration scratch (finest level)
+    float *x0 = nullptr, *x1 = nullptr, *x2 = nullptr, *cr = nullptr, *cx = nullptr;   // x1, x2: eigenvalue-estimate scratch (finest level)
     double *cdense = nullptr, *cinv = nullptr, *cglob = nullptr;   // the coarsest solve stays in double
     double* gj = nullptr;        // 2 * 1024 doubles of Gauss-Jordan scratch
     // Replicated coarse part of a decomposed hierarchy: from the first level whose GLOBAL size is small enough, the
@@ -399,6 +403,7 @@ struct Comm {
     shk_allreduce_fn cb_allreduce = nullptr;
     void* cb_user = nullptr;
     std::vector<HaloPlan> plans;             // [0] fine level, [l] multigrid level l (distributed hierarchy)
+    int64_t n_exchange = 0, n_allreduce = 0, bytes_exchange = 0, bytes_allreduce = 0;   // message rounds since creation
     double* d_sendbuf = nullptr;             // sized for plans[0], the largest
     double* d_recvbuf = nullptr;             // staging of a float vector's ghosts (they travel as doubles)
     double *h_send = nullptr, *h_recv = nullptr, *h_red = nullptr;  // pinned staging (CALLBACK)
@@ -408,7 +413,8 @@ struct Comm {
 struct Ctx {
     int device = 0;
     Comm comm;
-    int np = 0;     // partial-array length every kernel reduces: grid, or kMaxParts across subdomains
+    int np = 0;     // entries of a reduction slot the consumers sum: grid (one context) or 1 (all-reduced scalars)
+    int red_stride = kMaxParts;   // distance between reduction slots in d_red: kMaxParts, or 1 across subdomains
     hipStream_t stream = nullptr;
     int64_t n_own = 0, n_loc = 0, ne = 0, nnz = 0, slots = 0;
     shk_params params{};
@@ -452,7 +458,9 @@ struct Ctx {
     float *d_phat = nullptr, *d_shat = nullptr;   // M^-1 p, M^-1 s: float, like everything the cycle produces
     bool use_amg = false;
     double* d_part = nullptr;  // 8 arrays of kMaxParts: this subdomain's partial sums
-    double* d_red = nullptr;   // the same summed over subdomains (== d_part for a single context)
+    double* d_red = nullptr;   // what the consumers read: d_part itself (one context), or P_COUNT scalars = this
+                               // subdomain's partial arrays summed in a fixed order, then all-reduced (48 B per
+                               // reduction point instead of 2-4 partial arrays of 16 KB)
     KrylovState* d_state = nullptr;
     KrylovState* h_state = nullptr;  // pinned, 2 slots
     double* h_part = nullptr;        // pinned, kMaxParts

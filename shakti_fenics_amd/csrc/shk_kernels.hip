@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kBlock) void k_bicg_init(int64_t n, const double* _
 }
 
 __global__ __launch_bounds__(kBlock) void k_bicg_s(int64_t n, int it, int max_it, double rtol2, double atol2,
-                                                   int np, const double* red, double* part,
+                                                   int np, int rs, const double* red, double* part,
                                                    const double* __restrict__ r, const double* __restrict__ v,
                                                    const double* __restrict__ rhat, double* __restrict__ s,
                                                    KrylovState* __restrict__ st) {
@@ -193,8 +193,10 @@ __global__ __launch_bounds__(kBlock) void k_bicg_s(int64_t n, int it, int max_it
     if (st->done) return;
     // ||r||^2 of the iterate that opened this iteration decides whether to go on (the test sits here,
     // one kernel after the first product, so that it shares that product's reduction point)
-    const double rr = reduce_partials(red + P_RR * kMaxParts, np, sh4);
-    const double rhv = reduce_partials(red + P_RHV * kMaxParts, np, sh4);
+    // red: slot X starts at red[X * rs]; np entries (one context: its own partial arrays, rs = kMaxParts, np = grid;
+    // several subdomains: the all-reduced scalars, rs = 1, np = 1)
+    const double rr = reduce_partials(red + P_RR * rs, np, sh4);
+    const double rhv = reduce_partials(red + P_RHV * rs, np, sh4);
     const double target2 = (it == 0) ? fmax(rtol2 * rr, atol2) : st->target2;
     const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
     if (lead && it == 0) { st->target2 = target2; st->rhs2 = rr; st->rho[0] = rr; }
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(kBlock) void k_bicg_s(int64_t n, int it, int max_it
 
 // Closes iteration `it` (it >= 0) and prepares p for iteration it+1.
 template <class TP>   // double: phat, shat alias p, s (Jacobi); float: the multigrid cycle's outputs
-__global__ __launch_bounds__(kBlock) void k_bicg_u(int64_t n, int it, int np, const double* red, double* part,
+__global__ __launch_bounds__(kBlock) void k_bicg_u(int64_t n, int it, int np, int rs, const double* red, double* part,
                                                    const double* __restrict__ s, const double* __restrict__ t,
                                                    const double* __restrict__ v, double* p, const TP* phat,
                                                    const TP* shat, double* __restrict__ y,
@@ -233,10 +235,10 @@ __global__ __launch_bounds__(kBlock) void k_bicg_u(int64_t n, int it, int np, co
     if (st->done) return;
     double ts = 0.0, tt = 0.0, rht = 0.0, rhs = 0.0;
     for (int i = threadIdx.x; i < np; i += kBlock) {
-        ts += red[P_TS * kMaxParts + i];
-        tt += red[P_TT * kMaxParts + i];
-        rht += red[P_RHT * kMaxParts + i];
-        rhs += red[P_RHS * kMaxParts + i];
+        ts += red[P_TS * rs + i];
+        tt += red[P_TT * rs + i];
+        rht += red[P_RHT * rs + i];
+        rhs += red[P_RHS * rs + i];
     }
     ts = block_sum(ts, sh4);
     tt = block_sum(tt, sh4);
@@ -326,7 +328,7 @@ hipError_t krylov_iteration(Ctx* c, int it) {
     {
         PhaseTimer t(c, SHK_PH_VECTOR);
         hipLaunchKernelGGL(k_bicg_s, g, b, 0, c->stream, c->n_own, it, c->params.krylov_max_it, c->cur_rtol2,
-                           c->cur_atol2, c->np, c->d_red, part, c->d_r, c->d_v, c->d_rhat, c->d_s, c->d_state);
+                           c->cur_atol2, c->np, c->red_stride, c->d_red, part, c->d_r, c->d_v, c->d_rhat, c->d_s, c->d_state);
     }
     if (amg) {
         if ((e = amg_vcycle(c, *c->amg, c->d_s, c->d_shat)) != hipSuccess) return e;
@@ -342,10 +344,10 @@ hipError_t krylov_iteration(Ctx* c, int it) {
     {
         PhaseTimer t(c, SHK_PH_VECTOR);
         if (amg)
-            hipLaunchKernelGGL(k_bicg_u<float>, g, b, 0, c->stream, c->n_own, it, c->np, c->d_red, part, c->d_s, c->d_t, c->d_v,
+            hipLaunchKernelGGL(k_bicg_u<float>, g, b, 0, c->stream, c->n_own, it, c->np, c->red_stride, c->d_red, part, c->d_s, c->d_t, c->d_v,
                                c->d_p, (const float*)c->d_phat, (const float*)c->d_shat, c->d_y, c->d_r, c->d_state);
         else
-            hipLaunchKernelGGL(k_bicg_u<double>, g, b, 0, c->stream, c->n_own, it, c->np, c->d_red, part, c->d_s, c->d_t, c->d_v,
+            hipLaunchKernelGGL(k_bicg_u<double>, g, b, 0, c->stream, c->n_own, it, c->np, c->red_stride, c->d_red, part, c->d_s, c->d_t, c->d_v,
                                c->d_p, (const double*)c->d_p, (const double*)c->d_s, c->d_y, c->d_r, c->d_state);
     }
     return hipSuccess;

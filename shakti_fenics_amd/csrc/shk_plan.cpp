@@ -312,7 +312,11 @@ std::string build_plan(int64_t n_own, int64_t n_loc, int64_t ne, const double* x
                 if (mark[c] != blk && seen[c] != s) { seen[c] = s; ++fresh; }
             }
         if (fresh > P.cells_max) return "one 64-row slice touches more cells than the assembly LDS budget";
-        if (slices_in > 0 && (slices_in >= P.slices_max || cells_in + fresh > P.cells_max)) close_block(s);
+        const int64_t slice_slots = A.ptr[s + 1] - A.ptr[s];
+        if (slice_slots > opt.slots_max) return "one 64-row slice has more SELL slots than an assembly block may own";
+        if (slices_in > 0 && (slices_in >= P.slices_max || cells_in + fresh > P.cells_max ||
+                              A.ptr[s + 1] - A.ptr[first_slice] > opt.slots_max))
+            close_block(s);
         for (int64_t v = ra; v < rb; ++v)
             for (int32_t k = v2c_ptr[v]; k < v2c_ptr[v + 1]; ++k) {
                 const int32_t c = v2c[k];

@@ -64,6 +64,7 @@ def make_context(sub: Subdomain, device: int, transport: str = "rccl", group=Non
         errs = [None] * sub.nranks
         dist.all_gather_object(errs, err, group=group)
         if any(errs):
+            ctx.close()   # free the mesh, matrix and hierarchy before the caller builds anything else
             raise _lib.ShaktiHipError("RCCL communicator could not be created: " + "; ".join(e for e in errs if e))
     elif transport == "gloo":
         ex, ar = gloo_callbacks(group)

@@ -41,7 +41,8 @@ _DEFAULTS = dict(
 # knobs that exist only in this build (the reference solves with DOLFINx defaults + sparse LU)
 _BUILD_KNOBS = dict(
     setup_file=None,            # optional path copied next to the results (solvers.py:125)
-    device=0, krylov_rtol=1e-10, krylov_max_it=20000,
+    device=None,                # GPU of this rank: set in __init__ from SHK_DEVICE / LOCAL_RANK (one process per GPU)
+    krylov_rtol=1e-10, krylov_max_it=20000,
     preconditioner="amg",       # "amg" (default) | "amg_local" | "jacobi" (north_star's solver)
     ingest="device",            # where interp_data / set_lake_bdry evaluate: "device" (HIP kernels, bit-identical to
                                 # scipy; raises without the built library or a GPU -- there is no silent fallback) |
@@ -67,6 +68,11 @@ class model_setup:
         for table in (_DEFAULTS, _BUILD_KNOBS):
             for name, value in table.items():
                 setattr(self, name, value)
+        import os
+        # one process per GPU: rank r of a node drives GPU LOCAL_RANK (SHK_DEVICE overrides, e.g. several ranks
+        # sharing one GPU over the host-staged transport in tests)
+        self.device = int(os.environ.get("SHK_DEVICE", os.environ.get("LOCAL_RANK", "0") if self.size > 1 else "0"))
+        self.transport = "rccl"     # halo / reduction transport of a multi-rank solve: "rccl" (xGMI) | "gloo" (host-staged)
 
     def set_lake_bdry(self, outline):
         """1 inside the lake outline, 0 outside (model_setup.py:68-72).  `outline` is an (m,2) polygon,

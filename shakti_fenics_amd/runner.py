@@ -11,18 +11,41 @@ from .mesh import rectangle_mesh
 from .synthetic import CONFIGS, N_BDRY, outflow_predicate, synthetic_fields
 
 
+KERNEL_SOURCES = ("shk_device.h", "shk_kernels.hip", "shk_assemble.hip", "shk_amg.hip", "shk_plan.cpp", "shk_plan.h")
+
+
+def kernel_source_hash() -> str:
+    """sha256 over the kernel sources: ties a committed counter measurement to the code it was taken on."""
+    import hashlib
+    import os
+    h = hashlib.sha256()
+    csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(csrc, name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def _pmc_traffic(config, nv):
     """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950
     calibration + WRITE_SIZE, separate passes; tools/pmc_probe.py, tools/pmc_to_json.py).  Counters cannot be
-    collected from inside bench.py, so the numbers of the matching configuration are read from profiles/."""
+    collected from inside bench.py, so the numbers of the matching configuration are read from profiles/ -- and
+    only trusted when that file was measured on THESE kernel sources (its kernel_source_sha256); otherwise the
+    traffic entries are null and `traffic_source` says why."""
     import json
     import os
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
                         f"pmc_traffic_{config}.json")
     if not config or not os.path.exists(path):
-        return {}
-    k = json.load(open(path))["kernels"]
-    out = {"source": f"profiles/pmc_traffic_{config}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+        return {"source": "no committed counter file for this configuration"}
+    doc = json.load(open(path))
+    have, now = doc.get("kernel_source_sha256"), kernel_source_hash()
+    if have != now:
+        return {"source": f"profiles/pmc_traffic_{config}.json was measured on other kernel sources "
+                          f"(sha256 {str(have)[:12]} != {now[:12]}): traffic dropped; rerun tools/collect_profiles.sh pmc"}
+    k = doc["kernels"]
+    out = {"source": f"profiles/pmc_traffic_{config}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+                     f"kernel sources sha256 {now[:12]})"}
     for key in ("amg_fine", "amg_first"):
         if key in k:
             out[key] = k[key]["hbm_bytes"]
@@ -53,6 +76,7 @@ class SingleRunner:
         c.set_field("q", sf["q_init"]); c.set_field("melt_n", np.zeros(self.dom.num_vertices))
         self.bc = locate_boundary_dofs(self.dom, outflow_predicate(self.dom))
         c.set_dirichlet(self.bc, N_BDRY)
+        self.transport = "none"
         st = c.plan_stats()
         self.nv_global, self.ne_global, self.nnz_global = st["nv"], st["ne"], st["nnz"]
         self.stats = st
@@ -111,7 +135,16 @@ class SingleRunner:
                     "traffic": pmc.get(phase)}
 
         legs = {"spmv": leg("spmv", b_spmv, "k_spmv<1|2> (SELL-64 SpMV + fused BiCGStab dots)"),
-                "assemble": leg("assemble", b_asm, "k_assemble<true> (fused residual + Jacobian)")}
+                "assemble": leg("assemble", b_asm, "k_assemble (fused residual + Jacobian)")}
+        # what the SpMV actually has to move: fp64 values, 16-bit column offsets on the slices that allow them (the plan
+        # reports the padded slot count), the float x of the multigrid cycle, y and the two dot operands in double
+        slots = self.stats["sell_slots"]
+        legs["spmv"]["needed_bytes"] = 8 * slots + 2 * slots + 16 * ((nv + 63) // 64) + 4 * nv + 8 * nv + 12 * nv
+        legs["spmv"]["needed_note"] = ("bytes this implementation must move per launch (padded SELL slots, 16-bit columns, float "
+                                       "x, double y and dot operands); `bytes_per_launch` is SURVEY.md 8d's algorithmic figure "
+                                       "(int32 columns, double x) that `achieved` is priced with")
+        legs["spmv"]["achieved_needed"] = legs["spmv"]["needed_bytes"] / (legs["spmv"]["avg_launch_ms"] * 1e-3) / 1e9 \
+            if legs["spmv"]["avg_launch_ms"] > 0 else 0.0
         if prof["amg_fine"]["launches"]:
             legs["amg_fine"] = leg("amg_fine", b_post, "k_amg_post<true> (finest-level multigrid smoother, SELL-64 SpMV)")
         if prof.get("amg_first", {}).get("launches"):
@@ -215,23 +248,27 @@ class PartitionedRunner(SingleRunner):
 
 
 def make_runner(args, rank: int, world: int, local_rank: int):
+    """The runner bench.py drives.  With several ranks the transport is what was asked for (--transport): if RCCL is
+    requested and cannot be used, this RAISES (on every rank: the failure is agreed on collectively) -- unless
+    --allow-host-staged was given, in which case the same solver runs over the host-staged gloo transport and
+    `run.transport` says so (a PCIe-staged number must never pass for an xGMI one)."""
     if world == 1:
         return SingleRunner(args.config, args.order, args.dt, bool(args.storage), args.moulins, local_rank,
                             args.krylov_rtol, precond=getattr(args, "precond", "amg"))
     transport = getattr(args, "transport", "rccl")
     kw = dict(precond=getattr(args, "precond", "amg"))
+    failure = None
     try:
         return PartitionedRunner(rank, world, local_rank, args.config, args.order, args.dt, bool(args.storage),
                                  args.moulins, args.krylov_rtol, transport=transport, **kw)
     except _lib.ShaktiHipError as exc:
-        if transport != "rccl" or "RCCL communicator" not in str(exc):
+        if transport != "rccl" or "RCCL communicator" not in str(exc) or not getattr(args, "allow_host_staged", False):
             raise
-        # The data path cannot use RCCL on this node (the error is collective: every rank is here).  Run the same
-        # solver over the host-staged transport instead of producing nothing, and say so in the workload string.
-        import sys
-        import torch.distributed as dist
-        print(f"[bench] WARNING rank {rank}: {exc}; continuing with the host-staged gloo transport", file=sys.stderr,
-              flush=True)
-        group = dist.new_group(backend="gloo")
-        return PartitionedRunner(rank, world, local_rank, args.config, args.order, args.dt, bool(args.storage),
-                                 args.moulins, args.krylov_rtol, transport="gloo", group=group, **kw)
+        failure = str(exc)   # leave the except block first: the traceback keeps the failed context's frames alive
+    import sys
+    import torch.distributed as dist
+    print(f"[bench] WARNING rank {rank}: {failure}; --allow-host-staged: continuing with the host-staged gloo transport",
+          file=sys.stderr, flush=True)
+    group = dist.new_group(backend="gloo")
+    return PartitionedRunner(rank, world, local_rank, args.config, args.order, args.dt, bool(args.storage),
+                             args.moulins, args.krylov_rtol, transport="gloo", group=group, **kw)

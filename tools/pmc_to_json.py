@@ -6,7 +6,10 @@ Corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE and WRITE_SIZE are in
 counts exactly half of the bytes of a streaming read -- verified in the same pass on `k_norm2` over the value
 array (a pure 8-B-per-lane streaming read of known size, tools/pmc_probe.py) -- so reads are doubled; WRITE_SIZE
 is exact for streaming stores.  Per-kernel value = median over the launches that did real work."""
-import collections, csv, json, statistics, sys
+import collections, csv, json, os, statistics, sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from shakti_fenics_amd.runner import kernel_source_hash
 
 fetch_csv, write_csv, calib_bytes, out = sys.argv[1], sys.argv[2], float(sys.argv[3]), sys.argv[4]
 
@@ -23,7 +26,7 @@ def per_kernel(path, ctr):
 F, W = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
 norm = max(F.get("shk::k_norm2(long, double const*, double*)", [0.0]))
 factor = calib_bytes / (norm * 1024.0) if norm else 2.0
-res = {"fetch_size_correction": factor, "calibration": {"kernel": "k_norm2 over the SELL value array",
+res = {"kernel_source_sha256": kernel_source_hash(), "fetch_size_correction": factor, "calibration": {"kernel": "k_norm2 over the SELL value array",
        "known_bytes": calib_bytes, "fetch_size_kib": norm}, "kernels": {}}
 want = {"k_amg_post<true": "amg_fine", "k_amg_first<true": "amg_first", "k_spmv<0": "spmv_plain", "k_spmv<1": "spmv1", "k_spmv<2": "spmv2",
         "k_assemble": "assemble", "k_bicg_u": "bicg_u", "k_bicg_s": "bicg_s"}
