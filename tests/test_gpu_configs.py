@@ -57,6 +57,31 @@ def _sampled_rows_check(r, dt, nsample=1500, seed=1):
     return wj / np.abs(va).max(), wf / max(np.abs(F[sample]).max(), 1e-300), float(np.linalg.norm(F))
 
 
+def test_c2_1m_dof_trajectory_matches_the_lu_oracle_sample():
+    """Trajectory parity at BASELINE's 1M-DOF size: three time steps (storage + 20 moulins) against the LU oracle's run
+    of the same case, which takes the build container ~18 minutes and is therefore committed as a SAMPLE
+    (tests/golden/make_golden_1m.py -> c2_1m_oracle_sample.npz: N, b, q, melt_n at 4117 vertices after every step, the
+    fields' norms, Newton counts).  Bar: 1e-7 on the sample and on the norms (north_star: 1e-6 on the head / N field)."""
+    from shakti_fenics_amd.runner import SingleRunner
+    g = np.load(os.path.join(ROOT, "tests", "golden", "c2_1m_oracle_sample.npz"))
+    r = SingleRunner("c2_1m", storage=True, moulins=int(g["moulins"]))
+    assert np.allclose([r.dom.xy.sum(), float(r.dom.cells.astype(np.int64).sum())], g["xy_checksum"], rtol=1e-14)
+    sample = g["sample"]
+    its = []
+    for i in range(3):
+        info = r.step(i)
+        its.append(info.newton_its)
+        k = f"step{i + 1}"
+        got = {"N": r.ctx.get_field("N"), "b": r.ctx.get_field("b"), "q": r.ctx.get_field("q"), "melt_n": r.ctx.get_field("melt_n")}
+        for j, name in enumerate(("N", "b", "q", "melt_n")):
+            ref = g[f"{k}_{name}"]
+            err = np.linalg.norm(got[name][sample] - ref) / np.linalg.norm(ref)
+            assert err < (1e-7 if name in ("N", "b") else 1e-6), (k, name, err)
+            assert abs(np.linalg.norm(got[name]) / g[k + "_norms"][j] - 1.0) < 1e-7, (k, name)
+    assert its == list(g["newton_its"])
+    r.close()
+
+
 def test_c3_1m_dof_1000_step_transient():
     from shakti_fenics_amd.runner import SingleRunner
     r = SingleRunner("c2_1m", storage=True, moulins=0)

@@ -102,14 +102,16 @@ def test_rccl_single_rank_communicator():
 def test_rccl_refusal_is_collective_and_falls_back_to_the_host_staged_transport():
     """Two ranks on ONE GPU ask for an RCCL communicator.  RCCL refuses duplicate devices, which exercises a real
     multi-rank bootstrap through the dlopen()ed library (id broadcast, ncclCommInitRank on both ranks), the
-    collective error report of distributed.make_context and the fallback of runner.make_runner: both ranks must
-    end up on the gloo transport and take the same solver decisions."""
+    collective error report of distributed.make_context (make_runner raises on BOTH ranks) and, with
+    --allow-host-staged, the fallback of runner.make_runner: both ranks end up on the gloo transport and take the same
+    solver decisions."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
            "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "tests", "rccl_shared_gpu_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stderr.count("RCCL communicator could not be created") >= 2
+    assert r.stdout.count("refused True") == 2          # no silent fallback: it takes --allow-host-staged
     import re
     lines = re.findall(r"rank (\d): transport gloo, step 0 newton (\d+) krylov (\d+)", r.stdout)
     assert sorted(l[0] for l in lines) == ["0", "1"] and lines[0][1:] == lines[1][1:]
