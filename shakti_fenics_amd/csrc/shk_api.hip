@@ -317,8 +317,7 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
 #define UP(dst, src) if ((e = upload(c, &c->dst, P.src)) != hipSuccess) return bail(e, "upload " #src)
     UP(d_cells, cells); UP(d_perm, perm); UP(d_sell_ptr, A.ptr); UP(d_sell_col, A.col); UP(d_rowlen, A.rowlen);
     UP(d_cbase, A.cbase); UP(d_ptr16, A.ptr16); UP(d_col16, A.col16);
-    UP(d_lastcell, lastcell); UP(d_blk_slice0, blk_slice0); UP(d_blk_cellptr, blk_cellptr);
-    UP(d_blk_haloptr, blk_haloptr); UP(d_blk_halo, blk_halo); UP(d_blk_cellv, blk_cellv);
+    UP(d_lastcell, lastcell); UP(d_blk_desc, blk_desc); UP(d_blk_halo, blk_halo); UP(d_blk_cellv, blk_cellv);
     UP(d_incptr, incptr); UP(d_inccode, inccode); UP(d_slotsrc, slotsrc);
 #undef UP
     // the host copies of the big plan arrays are no longer needed (the SELL pattern stays for get_csr)

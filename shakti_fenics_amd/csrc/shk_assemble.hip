@@ -208,28 +208,32 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
 
     const int blk = xcd_block(blockIdx.x, gridDim.x);
     const int tid = threadIdx.x;
-    const int s0 = a.blk_slice0[blk], ns = a.blk_slice0[blk + 1] - s0;
+    // one descriptor (scalar loads) names everything this workgroup fetches: all its other loads depend on nothing else
+    const int32_t* __restrict__ dsc = a.blk_desc + (size_t)kBlkDesc * blk;
+    const int s0 = dsc[0], ns = dsc[1], c0 = dsc[2], ncell = dsc[3], h0 = dsc[4], nhalo = dsc[5];
+    const int n0 = dsc[6], n1 = dsc[7], ip0 = dsc[8], ninc = dsc[9];
     const int r0 = s0 * kSlice;
     const int r1 = min(a.A.n_rows, (s0 + ns) * kSlice);
     const int nrows = r1 - r0;
-    const int c0 = a.blk_cellptr[blk], ncell = a.blk_cellptr[blk + 1] - c0;
-    const int h0 = a.blk_haloptr[blk], nhalo = a.blk_haloptr[blk + 1] - h0;
 
     // ---- phase 0: stage plan slices, quadrature tables and the fields of the block's vertices ----
-    // the plan words of this thread's slots (phase 2) are requested first: they arrive while phase 1 computes
+    // the plan words of this thread's slots (phase 2) and its cells' vertex ids (phase 1) are requested first: they
+    // arrive while the fields are staged / while phase 1 computes
     constexpr int kSlotIt = (kAsmSlotsMax + T - 1) / T;
     uint32_t srcw[kSlotIt];
-    {
-        const int n0 = a.A.ptr[s0], n1 = a.A.ptr[s0 + ns];
 #pragma unroll
-        for (int r = 0; r < kSlotIt; ++r) {
-            const int s = n0 + tid + r * T;
-            srcw[r] = s < n1 ? a.slotsrc[s] : kSrcEmpty;
-        }
+    for (int r = 0; r < kSlotIt; ++r) {
+        const int s = n0 + tid + r * T;
+        srcw[r] = s < n1 ? a.slotsrc[s] : kSrcEmpty;
+    }
+    ushort4 cvw[R];
+    {
+        const ushort4* __restrict__ cellv = reinterpret_cast<const ushort4*>(a.blk_cellv) + c0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) cvw[r] = tid + r * T < ncell ? cellv[tid + r * T] : make_ushort4(0, 0, 0, 0);
     }
     for (int i = tid; i <= ns; i += T) sp[i] = a.A.ptr[s0 + i];
     for (int i = tid; i <= nrows; i += T) ip[i] = a.incptr[r0 + i];
-    const int ip0 = a.incptr[r0], ninc = a.incptr[r1] - ip0;
     for (int i = tid; i < ninc; i += T) ic[i] = a.inccode[ip0 + i];
     if (tid < a.quad.nq) qk[tid] = QPoint{a.quad.phi0[tid], a.quad.phi1[tid], a.quad.phi2[tid], a.quad.w2[tid]};
     if (tid >= 64 && tid - 64 < a.qpoly.nq) {
@@ -269,12 +273,11 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
 
     // ---- phase 1: one thread per cell touching the owned rows; tensors stay in registers until all fields are read ----
     CellOut out[R];
-    const ushort4* __restrict__ cellv = reinterpret_cast<const ushort4*>(a.blk_cellv) + c0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int t = tid + r * T;
         if (t < ncell) {
-            const ushort4 cv = cellv[t];
+            const ushort4 cv = cvw[r];
             if (a.ablate & 1) {
 #pragma unroll
                 for (int k = 0; k < 9; ++k) out[r].K[k] = fld[cv.x] + k;
@@ -300,7 +303,6 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
 
     // ---- phase 2a: one thread per SELL slot of the owned slices ----
     if (!(a.ablate & 2)) {
-        const int n0 = sp[0], n1 = sp[ns];
 #pragma unroll
         for (int r = 0; r < kSlotIt; ++r) {
             const int s = n0 + tid + r * T;
@@ -378,8 +380,7 @@ static void fill_asm_args(Ctx* c, double dt, AsmArgs& a) {
     a.bc_value = c->bc_value;
     a.inv_rwg_dt = 1.0 / (c->dp.rwg * dt);
     a.A = c->sell();
-    a.blk_slice0 = c->d_blk_slice0; a.blk_cellptr = c->d_blk_cellptr; a.blk_haloptr = c->d_blk_haloptr;
-    a.blk_halo = c->d_blk_halo; a.blk_cellv = c->d_blk_cellv;
+    a.blk_desc = c->d_blk_desc; a.blk_halo = c->d_blk_halo; a.blk_cellv = c->d_blk_cellv;
     a.incptr = c->d_incptr; a.inccode = c->d_inccode;
     a.cells_max = c->plan.cells_max; a.slices_max = c->plan.slices_max; a.verts_max = c->plan.verts_max;
     a.inc_max = c->plan.max_inc_per_block;

@@ -268,7 +268,7 @@ struct AsmArgs {
     double bc_value;
     double inv_rwg_dt;       // 1 / (rho_w g dt)
     DevSell A;
-    const int32_t *blk_slice0, *blk_cellptr, *blk_haloptr, *blk_halo, *incptr;
+    const int32_t *blk_desc, *blk_halo, *incptr;   // blk_desc: kBlkDesc ints per block (shk_plan.h)
     const uint16_t *blk_cellv, *inccode;
     int cells_max;           // LDS stride E of the element tensors
     int verts_max;           // LDS stride V of the staged fields
@@ -439,8 +439,7 @@ struct Ctx {
     uint8_t* d_rowlen = nullptr;
     int32_t *d_cbase = nullptr, *d_ptr16 = nullptr;
     uint16_t* d_col16 = nullptr;
-    int32_t *d_blk_slice0 = nullptr, *d_blk_cellptr = nullptr, *d_blk_haloptr = nullptr, *d_blk_halo = nullptr,
-            *d_incptr = nullptr;
+    int32_t *d_blk_desc = nullptr, *d_blk_halo = nullptr, *d_incptr = nullptr;
     uint16_t *d_inccode = nullptr, *d_blk_cellv = nullptr;
     int nblk = 0;
     int64_t cells_staged = 0;  // cells computed per assembly incl. those shared between blocks

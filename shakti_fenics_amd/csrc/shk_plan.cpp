@@ -326,6 +326,20 @@ std::string build_plan(int64_t n_own, int64_t n_loc, int64_t ne, const double* x
     }
     close_block(A.nslice);
     if (!plan_error.empty()) return plan_error;
+    {
+        const int32_t nblk = (int32_t)P.blk_slice0.size() - 1;
+        P.blk_desc.assign((size_t)kBlkDesc * nblk, 0);
+        for (int32_t b = 0; b < nblk; ++b) {
+            int32_t* d = &P.blk_desc[(size_t)kBlkDesc * b];
+            const int32_t s0 = P.blk_slice0[b], s1 = P.blk_slice0[b + 1];
+            const int64_t r0 = (int64_t)s0 * kSlice, r1 = std::min<int64_t>(n_own, (int64_t)s1 * kSlice);
+            d[0] = s0; d[1] = s1 - s0;
+            d[2] = P.blk_cellptr[b]; d[3] = P.blk_cellptr[b + 1] - P.blk_cellptr[b];
+            d[4] = P.blk_haloptr[b]; d[5] = P.blk_haloptr[b + 1] - P.blk_haloptr[b];
+            d[6] = A.ptr[s0]; d[7] = A.ptr[s1];
+            d[8] = P.incptr[r0]; d[9] = P.incptr[r1] - P.incptr[r0];
+        }
+    }
     if (opt.amg) {
         std::string err = build_amg(P, opt);
         if (!err.empty()) return err;

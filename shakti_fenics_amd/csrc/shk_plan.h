@@ -17,6 +17,7 @@
 namespace shk {
 
 constexpr int kSlice = 64;  // rows per SELL slice = wavefront width
+constexpr int kBlkDesc = 12;               // ints per assembly-block descriptor (10 used, 48-byte stride)
 constexpr uint32_t kSrcNone = 0x3FFu;      // slotsrc: cell slot meaning "no source"
 constexpr uint32_t kSrcEmpty = (kSrcNone << 4) | (kSrcNone << 18);   // a slot without sources, Dirichlet code 0
 
@@ -101,6 +102,9 @@ struct HostPlan {
     std::vector<int32_t> blk_halo;     // internal vertex ids, ascending inside a block
     std::vector<uint16_t> blk_cellv;   // 4 per staged cell: local ids of its three vertices, 0
     int verts_max = 0;                 // largest rows + halo of a block (LDS stride of the staged fields)
+    std::vector<int32_t> blk_desc;     // kBlkDesc ints per block: first slice, slices, first staged cell, cells, first
+                                       // halo entry, halo vertices, first SELL slot, end slot, first incidence entry,
+                                       // incidence entries -- ONE load tells a workgroup everything it fetches next
 };
 
 // xy: (n_loc,2) external order; cells: (ne,3) external local ids, every cell must touch at least one

@@ -47,7 +47,7 @@ def test_single_part_has_no_ghosts():
     assert s.n_ghost == 0 and s.nbr.size == 0 and s.n_own == dom.num_vertices
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_partitioned_path_over_gloo(world):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
