@@ -40,15 +40,15 @@ __device__ __forceinline__ double head_diff(double dzb, double dzs, double dN, c
     return dzb + p.ri_rw * (dzs - dzb) - dN / p.rwg;
 }
 
-// sqrt(s) for s >= 0 well inside the double range (|q|^2): rsq + the compiler's own refinement, without its
-// range scaling.  ~1 ulp.
+// sqrt(s) for s >= 0 well inside the double range (|q|^2): rsq, one coupled Goldschmidt step and one residual
+// correction, without the compiler's range scaling (hipcc's sqrt: 15 instructions, this: 9).  <= 1 ulp on the
+// inputs that matter; the result only enters through 1 + (omega / nu) sqrt(s).
 __device__ __forceinline__ double sqrt_nn(double s) {
     const double y = __builtin_amdgcn_rsq(s);
     double g = s * y, h = 0.5 * y;
     const double r = __builtin_fma(-h, g, 0.5);
     g = __builtin_fma(g, r, g);
     h = __builtin_fma(h, r, h);
-    g = __builtin_fma(__builtin_fma(-g, g, s), h, g);
     g = __builtin_fma(__builtin_fma(-g, g, s), h, g);
     return s > 0.0 ? g : 0.0;
 }
@@ -89,11 +89,13 @@ __device__ __forceinline__ void cell_tensor(const AsmArgs& a, const double* __re
     const double qy0 = LD(AF_QY, l0), qy1 = LD(AF_QY, l1), qy2 = LD(AF_QY, l2);
     // WaterFlux with the Reynolds switch, constitutive.py:11-20: q_w = -K grad(h); sK = int K dx
     double sK = 0.0;
+    // (a P1 field at a quadrature point: f0 + (f1 - f0) phi1 + (f2 - f0) phi2 -- two FMAs per field and point)
+    const double db1 = b1 - b0, db2 = b2 - b0, dqx1 = qx1 - qx0, dqx2 = qx2 - qx0, dqy1 = qy1 - qy0, dqy2 = qy2 - qy0;
     auto flux_point = [&](int k) {
         const QPoint q = qk[k];
-        const double bk = b0 * q.f0 + b1 * q.f1 + b2 * q.f2;
-        const double qxk = qx0 * q.f0 + qx1 * q.f1 + qx2 * q.f2;
-        const double qyk = qy0 * q.f0 + qy1 * q.f1 + qy2 * q.f2;
+        const double bk = __builtin_fma(db2, q.f2, __builtin_fma(db1, q.f1, b0));
+        const double qxk = __builtin_fma(dqx2, q.f2, __builtin_fma(dqx1, q.f1, qx0));
+        const double qyk = __builtin_fma(dqy2, q.f2, __builtin_fma(dqy1, q.f1, qy0));
         const double qn = sqrt_nn(qxk * qxk + qyk * qyk);
         const double ab = fabs(bk);
         sK += div_ge1(q.w * (ab * ab * ab), 1.0 + p.om_nu * qn);
@@ -112,7 +114,7 @@ __device__ __forceinline__ void cell_tensor(const AsmArgs& a, const double* __re
     const double dh1 = head_diff(LD(AF_ZB, l1) - zb0, LD(AF_ZS, l1) - zs0, N1 - N0, p);
     const double dh2 = head_diff(LD(AF_ZB, l2) - zb0, LD(AF_ZS, l2) - zs0, N2 - N0, p);
     const double ghx = dh1 * g1x + dh2 * g2x, ghy = dh1 * g1y + dh2 * g2y;
-    const double gbx = (b1 - b0) * g1x + (b2 - b0) * g2x, gby = (b1 - b0) * g1y + (b2 - b0) * g2y;
+    const double gbx = db1 * g1x + db2 * g2x, gby = db1 * g1y + db2 * g2y;
     const double gmx = (m1_ - m0_) * g1x + (m2_ - m0_) * g2x, gmy = (m1_ - m0_) * g1y + (m2_ - m0_) * g2y;
     const double gb2 = gbx * gbx + gby * gby;
     const double inv_den = 1.0 / (1.0 + gb2);
@@ -127,18 +129,21 @@ __device__ __forceinline__ void cell_tensor(const AsmArgs& a, const double* __re
     double T00 = 0.0, T01 = 0.0, T02 = 0.0, T11 = 0.0, T12 = 0.0, T22 = 0.0;
     const double qgh0 = p.rwg * (qx0 * ghx + qy0 * ghy), qgh1 = p.rwg * (qx1 * ghx + qy1 * ghy),
                  qgh2 = p.rwg * (qx2 * ghx + qy2 * ghy);  // rho_w g q.grad(h) is P1: interpolate its nodal values
+    const double dN1 = N1 - N0, dN2 = N2 - N0, dNn1 = Nn1 - Nn0, dNn2 = Nn2 - Nn0, dG1 = G1 - G0, dG2 = G2 - G0;
+    const double dm1 = m1_ - m0_, dm2 = m2_ - m0_, ds1 = s1 - s0, ds2 = s2 - s0, di1 = i1 - i0, di2 = i2 - i0;
+    const double dg1 = qgh1 - qgh0, dg2 = qgh2 - qgh0;
     auto poly_point = [&](int k) {
         const QPoint q = qp[k];
         const double f0 = q.f0, f1 = q.f1, f2 = q.f2;
         const double w = q.w * area;
-        const double Nk = N0 * f0 + N1 * f1 + N2 * f2;
-        const double Nnk = Nn0 * f0 + Nn1 * f1 + Nn2 * f2;
-        const double bk = b0 * f0 + b1 * f1 + b2 * f2;
-        const double Gk = G0 * f0 + G1 * f1 + G2 * f2;
-        const double mk = m0_ * f0 + m1_ * f1 + m2_ * f2;
-        const double sk = s0 * f0 + s1 * f1 + s2 * f2;
-        const double ik = i0 * f0 + i1 * f1 + i2 * f2;
-        const double qghk = qgh0 * f0 + qgh1 * f1 + qgh2 * f2;
+        const double Nk = __builtin_fma(dN2, f2, __builtin_fma(dN1, f1, N0));
+        const double Nnk = __builtin_fma(dNn2, f2, __builtin_fma(dNn1, f1, Nn0));
+        const double bk = __builtin_fma(db2, f2, __builtin_fma(db1, f1, b0));
+        const double Gk = __builtin_fma(dG2, f2, __builtin_fma(dG1, f1, G0));
+        const double mk = __builtin_fma(dm2, f2, __builtin_fma(dm1, f1, m0_));
+        const double sk = __builtin_fma(ds2, f2, __builtin_fma(ds1, f1, s0));
+        const double ik = __builtin_fma(di2, f2, __builtin_fma(di1, f1, i0));
+        const double qghk = __builtin_fma(dg2, f2, __builtin_fma(dg1, f1, qgh0));
         // Melt, constitutive.py:22-27 (div of the cell-wise P1 product expanded)
         const double melt = (Gk - qghk) / p.Lh + (mk * gb2 + bk * gmgb) * inv_den;
         const double pw = p.n_is_3 ? Nk * Nk : pow(fabs(Nk), p.n - 1.0);   // |N|^(n-1), constitutive.py:31
@@ -196,10 +201,15 @@ template <int T, int NQ, int NP>
 __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) {
     constexpr int R = (kAsmCellsMax + T - 1) / T;   // cells per thread
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int E = a.cells_max, V = a.verts_max;
+    constexpr int RH = R > 2 ? 2 : R;          // rounds whose tensors wait in registers (the rest goes to `eo` at once)
+    constexpr int E = RH * T;                  // cells (and stride) of the region shared with the fields
+    constexpr int EO = kAsmCellsMax > E ? kAsmCellsMax - E : 1;   // cells (and stride) of the overflow region
+    const int V = a.verts_max;
     double* fld = reinterpret_cast<double*>(smem);                  // [13][V] staged fields ...
-    double* et = fld;                                               // ... later [12][E] element tensors (same region)
-    QPoint* qk = reinterpret_cast<QPoint*>(smem + a.lds_region_a);
+    double* et = fld;                                               // ... later [12][E] element tensors of cells < E
+    double* eo = reinterpret_cast<double*>(smem + a.lds_region_a);  // [12][EO] element tensors of cells >= E (third
+                                                                    // round: written directly, it never overlaps fields)
+    QPoint* qk = reinterpret_cast<QPoint*>(eo + 12 * EO);
     QPoint* qp = qk + kMaxQuad;
     int* sp = reinterpret_cast<int*>(qp + kMaxQuad);                // [slices_max+1] SELL ptr of owned slices
     int* ip = sp + (a.slices_max + 1);                              // [rows+1] incptr of owned rows
@@ -217,8 +227,7 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
     const int nrows = r1 - r0;
 
     // ---- phase 0: stage plan slices, quadrature tables and the fields of the block's vertices ----
-    // the plan words of this thread's slots (phase 2) and its cells' vertex ids (phase 1) are requested first: they
-    // arrive while the fields are staged / while phase 1 computes
+    // the plan words of this thread's slots (phase 2) are requested first: they arrive while phase 1 computes
     constexpr int kSlotIt = (kAsmSlotsMax + T - 1) / T;
     uint32_t srcw[kSlotIt];
 #pragma unroll
@@ -226,12 +235,7 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
         const int s = n0 + tid + r * T;
         srcw[r] = s < n1 ? a.slotsrc[s] : kSrcEmpty;
     }
-    ushort4 cvw[R];
-    {
-        const ushort4* __restrict__ cellv = reinterpret_cast<const ushort4*>(a.blk_cellv) + c0;
-#pragma unroll
-        for (int r = 0; r < R; ++r) cvw[r] = tid + r * T < ncell ? cellv[tid + r * T] : make_ushort4(0, 0, 0, 0);
-    }
+    const ushort4* __restrict__ cellv = reinterpret_cast<const ushort4*>(a.blk_cellv) + c0;
     for (int i = tid; i <= ns; i += T) sp[i] = a.A.ptr[s0 + i];
     for (int i = tid; i <= nrows; i += T) ip[i] = a.incptr[r0 + i];
     for (int i = tid; i < ninc; i += T) ic[i] = a.inccode[ip0 + i];
@@ -272,25 +276,33 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
     __syncthreads();
 
     // ---- phase 1: one thread per cell touching the owned rows; tensors stay in registers until all fields are read ----
-    CellOut out[R];
+    CellOut out[RH];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int t = tid + r * T;
         if (t < ncell) {
-            const ushort4 cv = cvw[r];
+            const ushort4 cv = cellv[t];
+            CellOut tmp;
+            CellOut& o = r < RH ? out[r < RH ? r : 0] : tmp;
             if (a.ablate & 1) {
 #pragma unroll
-                for (int k = 0; k < 9; ++k) out[r].K[k] = fld[cv.x] + k;
+                for (int k = 0; k < 9; ++k) o.K[k] = fld[cv.x] + k;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) out[r].F[k] = fld[cv.y] + fld[cv.z];
+                for (int k = 0; k < 3; ++k) o.F[k] = fld[cv.y] + fld[cv.z];
             } else {
-                cell_tensor<NQ, NP>(a, fld, bcf, qk, qp, V, cv.x, cv.y, cv.z, out[r]);
+                cell_tensor<NQ, NP>(a, fld, bcf, qk, qp, V, cv.x, cv.y, cv.z, o);
+            }
+            if (r >= RH) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) eo[k * EO + (t - E)] = tmp.K[k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) eo[(9 + k) * EO + (t - E)] = tmp.F[k];
             }
         }
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
+    for (int r = 0; r < RH; ++r) {
         const int t = tid + r * T;
         if (t < ncell) {
 #pragma unroll
@@ -300,16 +312,18 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
         }
     }
     __syncthreads();
+    auto tensor = [&](int k, int cell) -> double { return cell < E ? et[k * E + cell] : eo[k * EO + (cell - E)]; };
 
     // ---- phase 2a: one thread per SELL slot of the owned slices ----
     if (!(a.ablate & 2)) {
+        // first slot of the block's 2nd .. 4th slice (INT_MAX when absent): a slot's slice by three compares
+        const int sp1 = ns > 1 ? sp[1] : 0x7FFFFFFF, sp2 = ns > 2 ? sp[2] : 0x7FFFFFFF, sp3 = ns > 3 ? sp[3] : 0x7FFFFFFF;
 #pragma unroll
         for (int r = 0; r < kSlotIt; ++r) {
             const int s = n0 + tid + r * T;
             if (s >= n1) break;
-            int j = 0;
-            while (j + 1 < ns && sp[j + 1] <= s) ++j;
-            const int off = s - sp[j];
+            const int j = (s >= sp1) + (s >= sp2) + (s >= sp3);
+            const int off = s - (j == 0 ? n0 : j == 1 ? sp1 : j == 2 ? sp2 : sp3);
             const int k = off >> 6, lane = off & 63;
             const int v = (s0 + j) * kSlice + lane;
             const uint32_t src = srcw[r];
@@ -320,13 +334,13 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
                     const int kb = ip[i] - ip0, ke = ip[i + 1] - ip0;
                     for (int q = kb; q < ke; ++q) {  // ascending cell id: fixed summation order
                         const int code = ic[q];
-                        sum += et[(4 * (code & 3)) * E + (code >> 2)];   // K_ii of that cell: li*3 + li
+                        sum += tensor(4 * (code & 3), code >> 2);   // K_ii of that cell: li*3 + li
                     }
                 }
             } else {
                 const uint32_t lo = src & 0x3FFFu, hi = (src >> 14) & 0x3FFFu;
-                if ((lo >> 4) != kSrcNone) sum = et[(lo & 15u) * E + (lo >> 4)];
-                if ((hi >> 4) != kSrcNone) sum += et[(hi & 15u) * E + (hi >> 4)];
+                if ((lo >> 4) != kSrcNone) sum = tensor(lo & 15u, lo >> 4);
+                if ((hi >> 4) != kSrcNone) sum += tensor(hi & 15u, hi >> 4);
             }
             const uint32_t bc = src >> 28;   // Dirichlet rows and columns zeroed, unit diagonal
             if (bc) sum = (bc == 2u) ? 1.0 : 0.0;
@@ -341,7 +355,7 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
         const int kb = ip[i] - ip0, ke = ip[i + 1] - ip0;
         for (int q = kb; q < ke; ++q) {
             const int code = ic[q];
-            sum += et[(9 + (code & 3)) * E + (code >> 2)];
+            sum += tensor(9 + (code & 3), code >> 2);
         }
         if (bcf[i]) sum = a.fld[0][v] - a.bc_value;  // set_bc(b, bcs, x, -1): F = N - g
         a.F[v] = sum;
@@ -395,11 +409,14 @@ static void fill_asm_args(Ctx* c, double dt, AsmArgs& a) {
 
 // LDS of one assembly workgroup: region A (staged fields, then the element tensors) + tables
 size_t assemble_lds_bytes(const HostPlan& P, size_t* region_a) {
-    const size_t E = P.cells_max, S = P.slices_max, V = P.verts_max;
+    const size_t S = P.slices_max, V = P.verts_max;
+    // region A: the staged fields, later the tensors of the first two rounds of cells (2 x 256; a 512-thread
+    // workgroup keeps every cell there); then the overflow tensors of the third round
+    const size_t E = 512, EO = kAsmCellsMax - 512;
     size_t ra = std::max((size_t)kAsmFields * V, 12 * E) * sizeof(double);
     ra = (ra + 15) & ~size_t(15);
     if (region_a) *region_a = ra;
-    size_t lds = ra + 2 * kMaxQuad * sizeof(QPoint) + (S + 1) * sizeof(int) + (S * kSlice + 1) * sizeof(int) +
+    size_t lds = ra + 12 * EO * sizeof(double) + 2 * kMaxQuad * sizeof(QPoint) + (S + 1) * sizeof(int) + (S * kSlice + 1) * sizeof(int) +
                  (size_t)P.max_inc_per_block * sizeof(uint16_t) + V;
     return (lds + 15) & ~size_t(15);
 }

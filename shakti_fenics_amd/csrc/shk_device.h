@@ -258,7 +258,7 @@ __device__ __forceinline__ void fused_restrict(const RestrictArgs& ra, int g, do
 
 constexpr int kAsmCellsMax = 640;   // cells one assembly workgroup stages (PlanOptions::cells_max is capped to it)
 constexpr int kAsmVertsMax = 768;   // vertices (own rows + halo) one assembly workgroup stages
-constexpr int kAsmSlotsMax = 4096;  // SELL slots of one assembly workgroup (4 slices x 64 rows x mean width <= 16)
+constexpr int kAsmSlotsMax = 3072;  // SELL slots of one assembly workgroup (4 slices x 64 rows x mean width <= 12)
 struct AsmArgs {
     Mesh m;
     const double* fld[11];   // N, N_n, b, qx, qy, z_b, z_s, G, melt_n, storage, inputs

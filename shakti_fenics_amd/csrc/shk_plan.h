@@ -24,7 +24,7 @@ constexpr uint32_t kSrcEmpty = (kSrcNone << 4) | (kSrcNone << 18);   // a slot w
 struct PlanOptions {
     int slices_max = 4;    // slices (of 64 rows) owned by one assembly block
     int cells_max = 640;   // cells staged in LDS by one assembly block
-    int slots_max = 4096;  // SELL slots one assembly block may own (its threads preload their plan words)
+    int slots_max = 3072;  // SELL slots one assembly block may own (its threads preload their plan words)
     int sort_window = 256; // rows per row-length sorting window (multiple of 64)
     bool reorder = true;   // internal k-d order + window sort (false: keep the caller's numbering)
     bool amg = true;       // also build the aggregation-multigrid hierarchy (of the owned diagonal block)

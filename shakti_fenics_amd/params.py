@@ -17,6 +17,3 @@ _SI = {
 globals().update({name: entry[0] for name, entry in _SI.items()})
 __all__ = sorted(_SI)
 
-
-def describe() -> str:
-    return "\n".join(f"{k:6s} = {v[0]:<10g} [{v[1]}]  {v[2]}" for k, v in _SI.items())

@@ -35,7 +35,10 @@ def _upload_inputs(ctx, md, storage, sel=None):
 
 
 def _configure(ctx, md):
-    ctx.set_params(b_min=float(md.b_min), krylov_rtol=float(getattr(md, "krylov_rtol", 1e-10)),
+    from . import params as P   # the constants a user edits, as in the reference (`from params import rho_i, rho_w, g`)
+    ctx.set_params(g=float(P.g), rho_i=float(P.rho_i), rho_w=float(P.rho_w), nu=float(P.nu), Lh=float(P.Lh),
+                   omega=float(P.omega), n=float(P.n), A=float(P.A),
+                   b_min=float(md.b_min), krylov_rtol=float(getattr(md, "krylov_rtol", 1e-10)),
                    krylov_max_it=int(getattr(md, "krylov_max_it", 20000)),
                    precond=_lib.PRECOND[getattr(md, "preconditioner", "amg")])  # collective when md.size > 1
 
@@ -173,8 +176,11 @@ def solve(md):
     newton_log, krylov_log = np.zeros(nt, dtype=np.int64), np.zeros(nt, dtype=np.int64)
     i_start = 0
     if restart:
-        # the reference has no resume path; this one continues bit for bit: the state after
-        # the last saved step is (N, b, q, melt_n) of that frame, and N_n = N
+        # the reference has no resume path.  The state after the last saved step is (N, b, q, melt_n)
+        # of that frame, and N_n = N: the resumed run continues from exactly that state.  It is bit-identical to the
+        # uninterrupted run when the multigrid's dense coarsest level has <= 512 rows (rebuilt at every solve: meshes up
+        # to ~200k DOF) or with the Jacobi preconditioner; on larger meshes the dense inverse is refreshed every 8th step,
+        # counted from the (re)start, so the two runs agree to the solver tolerance (1e-10 per linear solve), not bit for bit
         state = None
         if md.rank == 0:
             prog = np.load(md.results_name + "/progress.npy")
@@ -215,7 +221,10 @@ def solve(md):
         np.save(md.results_name + "/melt_n.npy", melt_arr)
         np.save(md.results_name + "/newton_its.npy", newton_log)
         np.save(md.results_name + "/krylov_its.npy", krylov_log)
-        np.save(md.results_name + "/progress.npy", np.array([j, last_saved_step]))
+        # progress marker last and atomically: a reader (md.restart) never sees it ahead of the arrays it describes
+        tmp = md.results_name + "/progress.tmp.npy"
+        np.save(tmp, np.array([j, last_saved_step]))
+        os.replace(tmp, md.results_name + "/progress.npy")
 
     last_saved_step = i_start - 1
     stop_after = getattr(md, "stop_after_step", None)   # optional: end the run early (tests, queue limits)
