@@ -183,7 +183,8 @@ int shk_time_kernel(shk_ctx* ctx, int32_t phase, int32_t reps, double dt, double
 /* Plan statistics for DESIGN.md / bench: n[0]=owned rows n[1]=ne n[2]=nnz n[3]=assembly blocks
  * n[4]=cells computed per assembly incl. cells shared between blocks n[5]=SELL slots (padded nnz)
  * n[6]=device bytes n[7]=max row length n[8]=entries of the finest A*P operator (0 if none)
- * n[9]=multigrid levels (sparse + dense) n[10]=rows of the dense coarsest level n[11]=reserved */
+ * n[9]=multigrid levels (sparse + dense) n[10]=rows of the dense coarsest level
+ * n[11]=LDS bytes of one assembly workgroup | (most vertices one stages << 32) */
 int shk_plan_stats(shk_ctx* ctx, int64_t n[12]);
 
 /* ---- setup-time data ingestion (context-free: host arrays in and out, caller's node order) ----

@@ -373,4 +373,6 @@ class ShaktiHip:
         self._check(self.lib.shk_plan_stats(self._h, n))
         keys = ("nv", "ne", "nnz", "asm_blocks", "asm_cells_computed", "sell_slots", "device_bytes", "max_row_len",
                 "ap_nnz", "amg_levels", "amg_dense_rows", "reserved")
-        return dict(zip(keys, [int(v) for v in n]))
+        d = dict(zip(keys, [int(v) for v in n]))
+        d["asm_lds_bytes"], d["asm_verts_max"] = d.pop("reserved") & 0xFFFFFFFF, int(n[11]) >> 32
+        return d

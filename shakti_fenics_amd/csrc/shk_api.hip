@@ -215,7 +215,8 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
             if ((e = dev_alloc(c, &H.cr, std::max<size_t>(64, std::max(rows, cols)))) != hipSuccess) return e;
             if ((e = dev_alloc(c, &H.cx, std::max<size_t>(64, rows))) != hipSuccess) return e;
             if ((e = dev_alloc(c, &H.cglob, std::max<size_t>(64, std::max(rows, cols)))) != hipSuccess) return e;
-            if ((e = dev_alloc(c, &H.gj, 2 * std::max<size_t>(1024, std::max(rows, cols)))) != hipSuccess) return e;
+            // scratch of the blocked Gauss-Jordan inverse: column panel, row panel, diagonal block (32 pivots)
+            if ((e = dev_alloc(c, &H.gj, (2 * std::max<size_t>(1024, std::max(rows, cols)) + 32) * 32)) != hipSuccess) return e;
         }
         LP = AmgLevelPlan();  // host copy no longer needed
     }
@@ -283,7 +284,6 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
     if (const char* s = getenv("SHK_ASM_CELLS")) opt.cells_max = std::max(64, atoi(s));
     opt.cells_max = std::min(opt.cells_max, kAsmCellsMax);
     opt.slots_max = kAsmSlotsMax;
-    if (const char* s = getenv("SHK_ASM_THREADS")) c->asm_threads = atoi(s) == 512 ? 512 : 256;
     if (const char* s = getenv("SHK_SORT_WINDOW")) opt.sort_window = std::max(64, atoi(s));
     if (const char* s = getenv("SHK_REORDER")) opt.reorder = atoi(s) != 0;
     if (const char* s = getenv("SHK_AMG")) opt.amg = atoi(s) != 0;
@@ -925,7 +925,7 @@ int shk_plan_stats(shk_ctx* ctx, int64_t n[12]) {
     n[8] = (H.ready() && H.xf[0].with_ap) ? H.ap_nnz0 : 0;
     n[9] = H.ready() ? (int64_t)H.xf.size() + 1 : 0;
     n[10] = H.ready() ? (H.distributed ? H.n_glob : H.xf.back().n_coarse) : 0;
-    n[11] = 0;
+    n[11] = (int64_t)c->asm_lds | ((int64_t)c->plan.verts_max << 32);   // LDS bytes of an assembly workgroup | its vertex stride
     return 0;
 }
 

@@ -201,15 +201,10 @@ template <int T, int NQ, int NP>
 __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) {
     constexpr int R = (kAsmCellsMax + T - 1) / T;   // cells per thread
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int RH = R > 2 ? 2 : R;          // rounds whose tensors wait in registers (the rest goes to `eo` at once)
-    constexpr int E = RH * T;                  // cells (and stride) of the region shared with the fields
-    constexpr int EO = kAsmCellsMax > E ? kAsmCellsMax - E : 1;   // cells (and stride) of the overflow region
-    const int V = a.verts_max;
+    const int E = a.cells_max, V = a.verts_max;
     double* fld = reinterpret_cast<double*>(smem);                  // [13][V] staged fields ...
-    double* et = fld;                                               // ... later [12][E] element tensors of cells < E
-    double* eo = reinterpret_cast<double*>(smem + a.lds_region_a);  // [12][EO] element tensors of cells >= E (third
-                                                                    // round: written directly, it never overlaps fields)
-    QPoint* qk = reinterpret_cast<QPoint*>(eo + 12 * EO);
+    double* et = fld;                                               // ... later [12][E] element tensors (same region)
+    QPoint* qk = reinterpret_cast<QPoint*>(smem + a.lds_region_a);
     QPoint* qp = qk + kMaxQuad;
     int* sp = reinterpret_cast<int*>(qp + kMaxQuad);                // [slices_max+1] SELL ptr of owned slices
     int* ip = sp + (a.slices_max + 1);                              // [rows+1] incptr of owned rows
@@ -276,33 +271,25 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
     __syncthreads();
 
     // ---- phase 1: one thread per cell touching the owned rows; tensors stay in registers until all fields are read ----
-    CellOut out[RH];
+    CellOut out[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int t = tid + r * T;
         if (t < ncell) {
             const ushort4 cv = cellv[t];
-            CellOut tmp;
-            CellOut& o = r < RH ? out[r < RH ? r : 0] : tmp;
             if (a.ablate & 1) {
 #pragma unroll
-                for (int k = 0; k < 9; ++k) o.K[k] = fld[cv.x] + k;
+                for (int k = 0; k < 9; ++k) out[r].K[k] = fld[cv.x] + k;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) o.F[k] = fld[cv.y] + fld[cv.z];
+                for (int k = 0; k < 3; ++k) out[r].F[k] = fld[cv.y] + fld[cv.z];
             } else {
-                cell_tensor<NQ, NP>(a, fld, bcf, qk, qp, V, cv.x, cv.y, cv.z, o);
-            }
-            if (r >= RH) {
-#pragma unroll
-                for (int k = 0; k < 9; ++k) eo[k * EO + (t - E)] = tmp.K[k];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) eo[(9 + k) * EO + (t - E)] = tmp.F[k];
+                cell_tensor<NQ, NP>(a, fld, bcf, qk, qp, V, cv.x, cv.y, cv.z, out[r]);
             }
         }
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < RH; ++r) {
+    for (int r = 0; r < R; ++r) {
         const int t = tid + r * T;
         if (t < ncell) {
 #pragma unroll
@@ -312,7 +299,7 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
         }
     }
     __syncthreads();
-    auto tensor = [&](int k, int cell) -> double { return cell < E ? et[k * E + cell] : eo[k * EO + (cell - E)]; };
+    auto tensor = [&](int k, int cell) -> double { return et[k * E + cell]; };
 
     // ---- phase 2a: one thread per SELL slot of the owned slices ----
     if (!(a.ablate & 2)) {
@@ -409,36 +396,28 @@ static void fill_asm_args(Ctx* c, double dt, AsmArgs& a) {
 
 // LDS of one assembly workgroup: region A (staged fields, then the element tensors) + tables
 size_t assemble_lds_bytes(const HostPlan& P, size_t* region_a) {
-    const size_t S = P.slices_max, V = P.verts_max;
-    // region A: the staged fields, later the tensors of the first two rounds of cells (2 x 256; a 512-thread
-    // workgroup keeps every cell there); then the overflow tensors of the third round
-    const size_t E = 512, EO = kAsmCellsMax - 512;
+    const size_t E = P.cells_max, S = P.slices_max, V = P.verts_max;
     size_t ra = std::max((size_t)kAsmFields * V, 12 * E) * sizeof(double);
     ra = (ra + 15) & ~size_t(15);
     if (region_a) *region_a = ra;
-    size_t lds = ra + 12 * EO * sizeof(double) + 2 * kMaxQuad * sizeof(QPoint) + (S + 1) * sizeof(int) + (S * kSlice + 1) * sizeof(int) +
+    size_t lds = ra + 2 * kMaxQuad * sizeof(QPoint) + (S + 1) * sizeof(int) + (S * kSlice + 1) * sizeof(int) +
                  (size_t)P.max_inc_per_block * sizeof(uint16_t) + V;
     return (lds + 15) & ~size_t(15);
-}
-
-template <int T>
-static void launch_T(Ctx* c, const AsmArgs& a, bool builtin) {
-    if (builtin) launch_phase(c, SHK_PH_ASSEMBLE, k_assemble<T, 15, 7>, dim3(c->nblk), dim3(T), c->asm_lds, a);
-    else launch_phase(c, SHK_PH_ASSEMBLE, k_assemble<T, 0, 0>, dim3(c->nblk), dim3(T), c->asm_lds, a);
 }
 
 void launch_assemble(Ctx* c, double dt) {
     AsmArgs a;
     fill_asm_args(c, dt, a);
+    // host-side check of what the kernel's fixed loop counts assume (a violation would write outside its LDS)
+    if (a.cells_max > kAsmCellsMax || a.verts_max > kAsmVertsMax) { set_error("assembly plan exceeds the kernel's staging limits"); return; }
     const bool builtin = a.quad.nq == 15 && a.qpoly.nq == 7;
-    if (c->asm_threads == 512) launch_T<512>(c, a, builtin);
-    else launch_T<256>(c, a, builtin);
+    if (builtin) launch_phase(c, SHK_PH_ASSEMBLE, k_assemble<kBlock, 15, 7>, dim3(c->nblk), dim3(kBlock), c->asm_lds, a);
+    else launch_phase(c, SHK_PH_ASSEMBLE, k_assemble<kBlock, 0, 0>, dim3(c->nblk), dim3(kBlock), c->asm_lds, a);
 }
 
 // Dynamic LDS above 64 KiB has to be requested per kernel.
 hipError_t prepare_kernels(Ctx* c) {
-    const void* fns[] = {reinterpret_cast<const void*>(&k_assemble<256, 15, 7>), reinterpret_cast<const void*>(&k_assemble<256, 0, 0>),
-                         reinterpret_cast<const void*>(&k_assemble<512, 15, 7>), reinterpret_cast<const void*>(&k_assemble<512, 0, 0>)};
+    const void* fns[] = {reinterpret_cast<const void*>(&k_assemble<kBlock, 15, 7>), reinterpret_cast<const void*>(&k_assemble<kBlock, 0, 0>)};
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->asm_lds);
         if (e != hipSuccess) return e;

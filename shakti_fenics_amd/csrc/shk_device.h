@@ -444,7 +444,6 @@ struct Ctx {
     int nblk = 0;
     int64_t cells_staged = 0;  // cells computed per assembly incl. those shared between blocks
     size_t asm_lds = 0, asm_region_a = 0;
-    int asm_threads = 256;     // workgroup size of k_assemble (SHK_ASM_THREADS = 256 | 512)
     double *d_F = nullptr, *d_vals = nullptr, *d_vals_s = nullptr, *d_dinv = nullptr;
     float *d_vals32 = nullptr, *d_dinv32 = nullptr;   // float copies read by the multigrid preconditioner
     // Krylov vectors

@@ -154,6 +154,37 @@ def test_three_steps_at_62k_dof_match_oracle(hip):
     ctx.close()
 
 
+def test_blocked_dense_inverse_equals_the_pivotwise_one(hip):
+    """The coarsest operator's inverse (977 rows on this 250k-DOF mesh) by the blocked Gauss-Jordan kernels and by the
+    pivot-by-pivot ones it replaced: the same preconditioner, hence the same Krylov iteration counts (+-1) and solution."""
+    import os
+    from shakti_fenics_amd.mesh import rectangle_mesh
+    from shakti_fenics_amd.synthetic import N_BDRY, outflow_predicate, synthetic_fields
+    dom = rectangle_mesh(1118, 224, 100e3, 20e3, order="morton")
+    sf = synthetic_fields(dom, storage_on=True, moulins=4)
+    nv = dom.num_vertices
+    f = O.Fields(N=sf["N_init"].copy(), N_n=sf["N_init"].copy(), b=np.abs(sf["b_init"]), q=sf["q_init"].copy(),
+                 melt_n=np.zeros(nv), z_b=sf["z_b"], z_s=sf["z_s"], G=sf["G"], storage=sf["lake_bdry"], inputs=sf["inputs"])
+    bc = O.boundary_dofs(dom.xy, dom.cells, outflow_predicate(dom))
+    out = {}
+    for mode in ("0", "1"):
+        os.environ["SHK_GJ_PIVOTWISE"] = mode
+        try:
+            ctx = hip.ShaktiHip(dom.xy, dom.cells)
+            ctx.set_params(precond=hip.PRECOND["amg"])
+            upload(ctx, f, bc, N_BDRY)
+            assert ctx.plan_stats()["amg_dense_rows"] > 64
+            ctx.assemble(360.0)
+            its, conv, rr = ctx.linear_solve()
+            assert conv
+            out[mode] = (its, ctx.get_field("dx"))
+            ctx.close()
+        finally:
+            del os.environ["SHK_GJ_PIVOTWISE"]
+    assert abs(out["0"][0] - out["1"][0]) <= 1, (out["0"][0], out["1"][0])
+    assert rel_l2(out["0"][1], out["1"][1]) < 1e-8
+
+
 def test_errors_are_loud(hip):
     dom, f, bc, g = make_case()
     ctx = hip.ShaktiHip(dom.xy, dom.cells)
