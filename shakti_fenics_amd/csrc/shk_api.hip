@@ -2,7 +2,9 @@
 // drivers.  Host code only decides "how many more iterations to enqueue"; every number the solve
 // produces is computed on the device.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <thread>
 #include <cstdio>
 #include <cstring>
 
@@ -310,6 +312,7 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "stream");
     if ((e = hipEventCreateWithFlags(&c->poll_ev[0], hipEventDisableTiming)) != hipSuccess) return bail(e, "event");
     if ((e = hipEventCreateWithFlags(&c->poll_ev[1], hipEventDisableTiming)) != hipSuccess) return bail(e, "event");
+    if ((e = hipEventCreateWithFlags(&c->poll_ev[2], hipEventDisableTiming)) != hipSuccess) return bail(e, "event");
     // mesh (internal numbering)
     if ((e = dev_alloc(c, &c->d_xy, nl)) != hipSuccess) return bail(e, "alloc xy");
     if ((e = hipMemcpy(c->d_xy, P.xy.data(), nl * sizeof(double2), hipMemcpyHostToDevice)) != hipSuccess)
@@ -547,6 +550,27 @@ int shk_get_csr(shk_ctx* ctx, int32_t* rowptr, int32_t* colidx, double* values) 
     return 0;
 }
 
+// Waiting on the device while RCCL collectives are in flight must not be able to hang forever: a peer that died or a
+// mismatched collective would otherwise block every rank inside hipEventSynchronize / hipStreamSynchronize with no
+// message.  With an RCCL communicator of > 1 ranks the host polls with a deadline (SHK_COMM_TIMEOUT_S, default 300 s)
+// and turns a stall into an error; single-GPU contexts block as usual.
+static hipError_t wait_event(Ctx* c, hipEvent_t ev) {
+    if (c->comm.kind != Comm::RCCL || c->comm.nranks <= 1) return hipEventSynchronize(ev);
+    static const double limit = getenv("SHK_COMM_TIMEOUT_S") ? atof(getenv("SHK_COMM_TIMEOUT_S")) : 300.0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) return hipErrorLaunchTimeOut;
+        std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+}
+static hipError_t wait_stream(Ctx* c) {
+    if (c->comm.kind != Comm::RCCL || c->comm.nranks <= 1) return hipStreamSynchronize(c->stream);
+    hipError_t e = hipEventRecord(c->poll_ev[2], c->stream);
+    return e != hipSuccess ? e : wait_event(c, c->poll_ev[2]);
+}
+
 // One BiCGStab run on A' y = rhs (x0 = 0).  The host only polls a stop flag: chunk k+1 is already queued
 // when chunk k's flag is read, so the GPU never idles; kernels after the stop return immediately.
 static int krylov_inner(Ctx* c, const double* rhs, int max_it, KrylovState* out) {
@@ -576,11 +600,14 @@ static int krylov_inner(Ctx* c, const double* rhs, int max_it, KrylovState* out)
         const int prev = slot;
         slot ^= 1;
         if ((e = enqueue(slot)) != hipSuccess) break;
-        if ((e = hipEventSynchronize(c->poll_ev[prev])) != hipSuccess) break;
+        if ((e = wait_event(c, c->poll_ev[prev])) != hipSuccess) break;
         if (c->h_state[prev].done) { *out = c->h_state[prev]; break; }
         if (it > max_it + 4 * chunk) { rc = fail("Krylov driver ran past max_it without a stop flag"); break; }
     }
     c->params.krylov_max_it = saved_max;
+    if (e == hipErrorLaunchTimeOut)
+        return fail("the Krylov loop stalled: no progress on the stream for SHK_COMM_TIMEOUT_S seconds with RCCL collectives in "
+                    "flight (a peer rank died, or the ranks diverged)");
     if (e != hipSuccess) return fail(std::string("krylov enqueue: ") + hipGetErrorString(e));
     return rc;
 }
@@ -588,7 +615,7 @@ static int krylov_inner(Ctx* c, const double* rhs, int max_it, KrylovState* out)
 static int read_aux_norm(Ctx* c, double* out) {  // fixed-order host sum of the (reduced) P_AUX partials
     HIPCHK(hipMemcpyAsync(c->h_part, c->d_red + (size_t)P_AUX * c->red_stride, (size_t)c->np * sizeof(double),
                           hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(wait_stream(c));
     double s = 0.0;
     for (int i = 0; i < c->np; ++i) s += c->h_part[i];
     *out = std::sqrt(s);

@@ -462,7 +462,7 @@ struct Ctx {
     KrylovState* d_state = nullptr;
     KrylovState* h_state = nullptr;  // pinned, 2 slots
     double* h_part = nullptr;        // pinned, kMaxParts
-    hipEvent_t poll_ev[2] = {nullptr, nullptr};
+    hipEvent_t poll_ev[3] = {nullptr, nullptr, nullptr};   // [0,1] stop-flag polls, [2] deadline waits
     bool assembled = false;
     double assembled_dt = 0.0;
     // profiling
