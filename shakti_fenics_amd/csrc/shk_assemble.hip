@@ -222,14 +222,6 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
     const int nrows = r1 - r0;
 
     // ---- phase 0: stage plan slices, quadrature tables and the fields of the block's vertices ----
-    // the plan words of this thread's slots (phase 2) are requested first: they arrive while phase 1 computes
-    constexpr int kSlotIt = (kAsmSlotsMax + T - 1) / T;
-    uint32_t srcw[kSlotIt];
-#pragma unroll
-    for (int r = 0; r < kSlotIt; ++r) {
-        const int s = n0 + tid + r * T;
-        srcw[r] = s < n1 ? a.slotsrc[s] : kSrcEmpty;
-    }
     const ushort4* __restrict__ cellv = reinterpret_cast<const ushort4*>(a.blk_cellv) + c0;
     for (int i = tid; i <= ns; i += T) sp[i] = a.A.ptr[s0 + i];
     for (int i = tid; i <= nrows; i += T) ip[i] = a.incptr[r0 + i];
@@ -286,6 +278,16 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
                 cell_tensor<NQ, NP>(a, fld, bcf, qk, qp, V, cv.x, cv.y, cv.z, out[r]);
             }
         }
+    }
+    // the plan words of this thread's slots (phase 2) are requested here -- after the element computation, whose
+    // registers they would otherwise crowd (they cost 80 B per lane of scratch spills = 0.8 GB of traffic per pass when
+    // requested at kernel start) -- and arrive while the tensors go to LDS
+    constexpr int kSlotIt = (kAsmSlotsMax + T - 1) / T;
+    uint32_t srcw[kSlotIt];
+#pragma unroll
+    for (int r = 0; r < kSlotIt; ++r) {
+        const int s = n0 + tid + r * T;
+        srcw[r] = s < n1 ? a.slotsrc[s] : kSrcEmpty;
     }
     __syncthreads();
 #pragma unroll
