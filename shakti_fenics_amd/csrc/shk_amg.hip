@@ -304,6 +304,24 @@ __global__ __launch_bounds__(kBlock) void k_amg_post(const AmgSmoothArgs<TX, TR,
     }
 }
 
+// Second visit of the doubled cycle: r <- r - A x (the level's residual after its first solution), x3 <- x.
+__global__ __launch_bounds__(kBlock) void k_amg_residual_save(const AmgSmoothArgs<float, float, float> a, float* __restrict__ rout) {
+    if (*a.done) return;
+    const int lane = threadIdx.x & 63;
+    for (SliceLoop it(a.A, wave_index()); it.valid(); it.next()) {
+        const int row = min(it.s * kSlice + lane, a.A.n_rows - 1);
+        const float xr = a.x[row];
+        const float rr = a.r[row];
+        const float sum = sell_row_sum(a.A, it.m, a.vals, a.x, lane);
+        if (it.s * kSlice + lane < a.A.n_rows) { rout[row] = rr - sum; a.xo[row] = xr; }
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_amg_add(int32_t n, const float* __restrict__ a, float* __restrict__ x,
+                                                    const int* __restrict__ done) {
+    if (*done) return;
+    for (int32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) x[i] += a[i];
+}
+
 // First smoothing sweep after the prolongation, without ever forming x0 = alpha P e:
 //   x1 = alpha e[agg] + w D^-1 (r - alpha (A P) e)       (A P has ~4 entries per row, e is 4x shorter than x)
 template <class TR>
@@ -962,32 +980,36 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
     ta.omega = w1; ta.omega2 = w2; ta.alpha = alpha; ta.done = done;
     ta.dense_in_tail = ta.ncols <= 128 ? 1 : 0;
     const int gemv_grid = std::min(2048, (ta.n_c + 3) / 4);
-    if (H.rep) {
-        // (done above)
-    } else if (H.distributed) {
-        {
+    auto bottom = [&]() -> hipError_t {
+        if (H.rep) {
+            // (done above)
+        } else if (H.distributed) {
+            {
+                PhaseTimer t(c, SHK_PH_AMG_COARSE);
+                if (ta.nlev > 0) hipLaunchKernelGGL(k_amg_tail<1>, dim3(1), dim3(kTailThreads), 0, c->stream, ta);
+                hipLaunchKernelGGL(k_coarse_scatter, dim3(1), dim3(kBlock), 0, c->stream, XL.n_coarse, H.offset, H.n_glob,
+                                   H.cr, H.cglob, done);
+            }
+            if ((e = allreduce_buffer(c, H.cglob, H.cglob, (size_t)H.n_glob)) != hipSuccess) return e;
+            PhaseTimer t(c, SHK_PH_AMG_COARSE);
+            if (!ta.dense_in_tail)
+                hipLaunchKernelGGL(k_dense_gemv<double>, dim3(gemv_grid), dim3(kBlock), 0, c->stream, ta.n_c, ta.row0,
+                                   ta.ncols, ta.inv, (const double*)H.cglob, ta.cx, done);
+            if (ta.nlev > 0 || ta.dense_in_tail) hipLaunchKernelGGL(k_amg_tail<2>, dim3(1), dim3(kTailThreads), 0, c->stream, ta);
+        } else if (ta.dense_in_tail) {
+            PhaseTimer t(c, SHK_PH_AMG_COARSE);
+            hipLaunchKernelGGL(k_amg_tail<0>, dim3(1), dim3(kTailThreads), 0, c->stream, ta);
+        } else {
             PhaseTimer t(c, SHK_PH_AMG_COARSE);
             if (ta.nlev > 0) hipLaunchKernelGGL(k_amg_tail<1>, dim3(1), dim3(kTailThreads), 0, c->stream, ta);
-            hipLaunchKernelGGL(k_coarse_scatter, dim3(1), dim3(kBlock), 0, c->stream, XL.n_coarse, H.offset, H.n_glob,
-                               H.cr, H.cglob, done);
+            hipLaunchKernelGGL(k_dense_gemv<float>, dim3(gemv_grid), dim3(kBlock), 0, c->stream, ta.n_c, ta.row0, ta.ncols,
+                               ta.inv, (const float*)H.cr, ta.cx, done);
+            if (ta.nlev > 0) hipLaunchKernelGGL(k_amg_tail<2>, dim3(1), dim3(kTailThreads), 0, c->stream, ta);
         }
-        if ((e = allreduce_buffer(c, H.cglob, H.cglob, (size_t)H.n_glob)) != hipSuccess) return e;
-        PhaseTimer t(c, SHK_PH_AMG_COARSE);
-        if (!ta.dense_in_tail)
-            hipLaunchKernelGGL(k_dense_gemv<double>, dim3(gemv_grid), dim3(kBlock), 0, c->stream, ta.n_c, ta.row0,
-                               ta.ncols, ta.inv, (const double*)H.cglob, ta.cx, done);
-        if (ta.nlev > 0 || ta.dense_in_tail) hipLaunchKernelGGL(k_amg_tail<2>, dim3(1), dim3(kTailThreads), 0, c->stream, ta);
-    } else if (ta.dense_in_tail) {
-        PhaseTimer t(c, SHK_PH_AMG_COARSE);
-        hipLaunchKernelGGL(k_amg_tail<0>, dim3(1), dim3(kTailThreads), 0, c->stream, ta);
-    } else {
-        PhaseTimer t(c, SHK_PH_AMG_COARSE);
-        if (ta.nlev > 0) hipLaunchKernelGGL(k_amg_tail<1>, dim3(1), dim3(kTailThreads), 0, c->stream, ta);
-        hipLaunchKernelGGL(k_dense_gemv<float>, dim3(gemv_grid), dim3(kBlock), 0, c->stream, ta.n_c, ta.row0, ta.ncols,
-                           ta.inv, (const float*)H.cr, ta.cx, done);
-        if (ta.nlev > 0) hipLaunchKernelGGL(k_amg_tail<2>, dim3(1), dim3(kTailThreads), 0, c->stream, ta);
-    }
-    for (size_t l = lt; l-- > 0;) {
+        return hipSuccess;
+    };
+    if ((e = bottom()) != hipSuccess) return e;
+    auto up_level = [&](size_t l) -> hipError_t {
         const AmgXfer& X = H.xf[l];
         const float* ec = X.dense ? H.cx : X.onto_global ? H.rep_xglob + H.rep_row0 : H.lv[l + 1].x2;
         const bool halo = H.distributed && (int)l < H.halo_levels;
@@ -1074,6 +1096,36 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
                 launch_post<false>(c, A, L.vals, L.dinv, (const float*)L.r, (const float*)L.x2, L.x, (float)(H.c4[2] / l4), done);
                 launch_post<false>(c, A, L.vals, L.dinv, (const float*)L.r, (const float*)L.x, L.x2, (float)(H.c4[3] / l4), done);
             }
+        }
+        return hipSuccess;
+    };
+    // Cycle doubling at ONE level (a W-cycle's second visit, at the level where visits cost launch latency, not
+    // bandwidth): after the level's first solution x1, the cycle below it runs again on r - A x1 and the two add up.
+    // Plain aggregation with piecewise-constant prolongation needs more than a V-cycle as the hierarchy deepens; a full
+    // W-cycle would visit the tiny levels 2^l times.  CPU prototype at 1M rows (same aggregates, sweeps, dampings):
+    // V 44 iterations, doubling at level 2 or 3 31, full W from level 1 22.  Single-context hierarchies only.
+    const size_t lw = (!H.distributed && !H.rep) ? H.w_level : 0;
+    for (size_t l = lt; l-- > 0;) {
+        if ((e = up_level(l)) != hipSuccess) return e;
+        if (l == lw && lw >= 1 && lw < lt) {
+            AmgLevel& L = H.lv[l];
+            const DevSell A = level_sell(c, H, l);
+            {
+                PhaseTimer t(c, SHK_PH_AMG_COARSE);
+                AmgSmoothArgs<float, float, float> ra{A, L.vals, L.dinv, L.r, L.x2, L.x3, 0.0f, done};
+                hipLaunchKernelGGL(k_amg_residual_save, dim3(std::min((A.nslice + 3) / 4, 2048)), dim3(kBlock), 0, c->stream, ra, L.r);
+                for (size_t ll = l; ll < lt; ++ll) {
+                    const AmgXfer& X = H.xf[ll];
+                    float* rc = X.dense ? H.cr : H.lv[ll + 1].r;
+                    hipLaunchKernelGGL(k_amg_restrict<float>, dim3(small_grid(X.n_coarse)), dim3(kBlock), 0, c->stream,
+                                       X.n_coarse, X.members, (const float*)H.lv[ll].r, rc, done);
+                }
+            }
+            if ((e = bottom()) != hipSuccess) return e;
+            for (size_t ll = lt; ll-- > l;)
+                if ((e = up_level(ll)) != hipSuccess) return e;
+            PhaseTimer t(c, SHK_PH_AMG_COARSE);
+            hipLaunchKernelGGL(k_amg_add, dim3(small_grid(L.n)), dim3(kBlock), 0, c->stream, L.n, (const float*)L.x3, L.x2, done);
         }
     }
     return hipSuccess;

@@ -204,7 +204,7 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
             if ((e = upload(c, &L.diag_slot, LP.diag_slot)) != hipSuccess) return e;
             const size_t nr = std::max<size_t>((size_t)L.nslice * kSlice, (size_t)L.n_cols);
             if ((e = dev_alloc(c, &L.vals, (size_t)L.slots)) != hipSuccess) return e;
-            float** vs[] = {&L.dinv, &L.x, &L.x2, &L.r};
+            float** vs[] = {&L.dinv, &L.x, &L.x2, &L.x3, &L.r};
             for (float** v : vs) {
                 if ((e = dev_alloc(c, v, nr)) != hipSuccess) return e;
                 if ((e = hipMemset(*v, 0, nr * sizeof(float))) != hipSuccess) return e;
@@ -225,6 +225,12 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
     if (const char* sa = getenv("SHK_AMG_ALPHA")) H.alpha = atof(sa);
     if (const char* sa = getenv("SHK_AMG_COARSE4")) H.coarse4 = atoi(sa) != 0;
     if (const char* sa = getenv("SHK_AMG_DENSE_PERIOD")) H.dense_period = std::max(1, atoi(sa));
+    {   // cycle doubling at the first sparse level of at most SHK_AMG_W_ROWS rows (default 200 000; 0: V-cycle)
+        const int64_t wrows = getenv("SHK_AMG_W_ROWS") ? atoll(getenv("SHK_AMG_W_ROWS")) : 200000;
+        H.w_level = 0;
+        for (size_t l = 1; l < nx && wrows > 0; ++l)
+            if (H.lv[l].n > 0 && H.lv[l].n <= wrows) { H.w_level = l; break; }
+    }
     if (const char* sa = getenv("SHK_AMG_DAMP_SCALE")) {   // robustness experiments: every damping of the cycle times f
         const double f = atof(sa);
         if (f > 0.0) { H.c1 *= f; H.c2 *= f; for (double& v : H.c4) v *= f; }

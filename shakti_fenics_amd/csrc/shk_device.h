@@ -298,7 +298,7 @@ struct AmgLevel {
     int32_t *ptr = nullptr, *col = nullptr, *diag_slot = nullptr, *cbase = nullptr, *ptr16 = nullptr;
     uint16_t* col16 = nullptr;
     uint8_t* rowlen = nullptr;
-    float *vals = nullptr, *dinv = nullptr, *x = nullptr, *x2 = nullptr, *r = nullptr;   // preconditioner precision
+    float *vals = nullptr, *dinv = nullptr, *x = nullptr, *x2 = nullptr, *x3 = nullptr, *r = nullptr;   // preconditioner precision
 };
 struct AmgXfer {  // level l -> l+1
     int32_t n_fine = 0, n_coarse = 0, n_coarse_cols = 0;
@@ -356,6 +356,7 @@ struct AmgHierarchy {
     // [0.25, 0.9] lambda, small and large steps interleaved.  Measured ms/step at 10M | 1M rows: two sweeps
     // 253 | 43.0; four with (c1, c2) twice 238 | 43.3; Chebyshev on [0.37, 0.77] 242 | 44, [0.25, 0.8] 230 | 39.4,
     // [0.2, 0.8] 223 | 41.5, [0.25, 0.9] 225 | 41.7; [0.15, 0.8] and [0.25, 0.7] diverge at 10M rows (SHK_AMG_COARSE4=0)
+    size_t w_level = 0;          // level whose cycle runs twice per visit (0: plain V-cycle); set at upload
     bool coarse4 = true;
     bool top_four = false;       // the top level is itself a coarse level of a larger cycle (replicated hierarchy)
     double c4[4] = {1.143, 3.640, 1.430, 2.219};
