@@ -1102,8 +1102,10 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
     // Cycle doubling at ONE level (a W-cycle's second visit, at the level where visits cost launch latency, not
     // bandwidth): after the level's first solution x1, the cycle below it runs again on r - A x1 and the two add up.
     // Plain aggregation with piecewise-constant prolongation needs more than a V-cycle as the hierarchy deepens; a full
-    // W-cycle would visit the tiny levels 2^l times.  CPU prototype at 1M rows (same aggregates, sweeps, dampings):
-    // V 44 iterations, doubling at level 2 or 3 31, full W from level 1 22.  Single-context hierarchies only.
+    // W-cycle would visit the tiny levels 2^l times.  A CPU prototype at 1M rows (same aggregates, sweeps, dampings, but a
+    // sparse coarsest level) promised 44 -> 31 iterations; on the real hierarchy, whose dense coarsest level of 977 /
+    // 2441 rows already solves the deep part exactly, it is 39.5 -> 35.4 at 1M rows and 45.8 -> 44.1 at 10M for 44 % / 5 %
+    // more time per step.  OFF by default (SHK_AMG_W_ROWS), single-context hierarchies only.
     const size_t lw = (!H.distributed && !H.rep) ? H.w_level : 0;
     for (size_t l = lt; l-- > 0;) {
         if ((e = up_level(l)) != hipSuccess) return e;
