@@ -313,7 +313,7 @@ std::string build_plan(int64_t n_own, int64_t n_loc, int64_t ne, const double* x
             }
         if (fresh > P.cells_max) return "one 64-row slice touches more cells than the assembly LDS budget";
         const int64_t slice_slots = A.ptr[s + 1] - A.ptr[s];
-        if (slice_slots > opt.slots_max) return "one 64-row slice has more SELL slots than an assembly block may own";
+        if (slice_slots > opt.slots_max) return "a vertex has more than 47 neighbours: SELL slices wider than 48 entries exceed the assembly kernel's slot budget";
         if (slices_in > 0 && (slices_in >= P.slices_max || cells_in + fresh > P.cells_max ||
                               A.ptr[s + 1] - A.ptr[first_slice] > opt.slots_max))
             close_block(s);
