@@ -222,7 +222,9 @@ def main():
             "dofs": nv, "cells": run.ne_global, "nnz": run.nnz_global,
             "newton_its": newton, "krylov_its": krylov,
             "krylov_its_per_newton": krylov / max(newton, 1),
-            "krylov": f"BiCGStab, right preconditioner {args.precond}, true-residual rtol {args.krylov_rtol:g}",
+            "krylov": f"BiCGStab, right preconditioner {args.precond}; every linear solve runs until its TRUE residual is below "
+                      f"max({args.krylov_rtol:g} ||F_k||, 0.1 x Newton's own stopping threshold max(1e-10, 1e-9 ||F_0||)) "
+                      "(shk_params.krylov_newton_eta; Newton counts equal the LU oracle's in every parity test)",
             "first_step": "0.1 dt (solvers.py:81); |b_init| instead of the reference's signed draw (DESIGN.md section 1)",
             "parallelism": f"dd{world}" if world > 1 else "single",
         },

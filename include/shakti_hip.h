@@ -39,6 +39,10 @@ typedef struct shk_params {
     double krylov_fail_rtol;    /* a linear solve whose true relative residual ends above this (or is not finite) is a
                                    FAILURE (shk_solve_info.krylov_failed); between krylov_rtol and this it has merely
                                    stagnated at its fp64 floor eps * || |J| |dx| ||, which Newton absorbs.  Default 1e-6 */
+    double krylov_newton_eta;   /* inside shk_newton_solve a linear solve also stops once its true residual is below
+                                   eta * max(newton_atol, newton_rtol ||F_0||): Newton's own stopping threshold, beyond
+                                   which more digits cannot change its decision.  Default 0.1 (= krylov_rtol ||F_0|| for
+                                   the first iteration); 0 = always solve to krylov_rtol ||F_k|| */
     int32_t newton_max_it;
     int32_t krylov_max_it;
     int32_t krylov_check_every; /* iterations enqueued between host stop-flag polls; 0 = automatic */

@@ -22,7 +22,7 @@ class ShaktiHipError(RuntimeError):
 class shk_params(C.Structure):
     _fields_ = [(n, C.c_double) for n in
                 ("g", "rho_i", "rho_w", "nu", "Lh", "omega", "n", "A", "b_min",
-                 "newton_rtol", "newton_atol", "newton_relax", "krylov_rtol", "krylov_atol", "krylov_fail_rtol")] + \
+                 "newton_rtol", "newton_atol", "newton_relax", "krylov_rtol", "krylov_atol", "krylov_fail_rtol", "krylov_newton_eta")] + \
                [(n, C.c_int32) for n in ("newton_max_it", "krylov_max_it", "krylov_check_every", "precond")]
 
 

@@ -262,6 +262,7 @@ int shk_default_params(shk_params* p) {
     // the reference solves each Newton system exactly (LU); the Krylov loop is driven to 1e-10
     p->krylov_rtol = 1e-10; p->krylov_atol = 1e-50; p->krylov_max_it = 20000; p->krylov_check_every = 0;
     p->krylov_fail_rtol = 1e-6;
+    p->krylov_newton_eta = 0.1;
     p->precond = SHK_PC_JACOBI;
     return 0;
 }
@@ -412,6 +413,7 @@ int shk_set_params(shk_ctx* ctx, const shk_params* p) {
     if (!(p->g > 0 && p->rho_i > 0 && p->rho_w > 0 && p->nu > 0 && p->Lh > 0)) return fail("non-positive constant");
     if (p->newton_max_it < 0 || p->krylov_max_it < 1 || p->krylov_check_every < 0) return fail("bad iteration limits");
     if (!(p->krylov_fail_rtol >= 0)) return fail("krylov_fail_rtol must be >= 0");
+    if (!(p->krylov_newton_eta >= 0 && p->krylov_newton_eta <= 1)) return fail("krylov_newton_eta must be in [0, 1]");
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (p->precond != SHK_PC_JACOBI && p->precond != SHK_PC_AMG && p->precond != SHK_PC_AMG_LOCAL)
         return fail("unknown preconditioner id");
@@ -632,14 +634,17 @@ static int read_aux_norm(Ctx* c, double* out) {  // fixed-order host sum of the 
 // Solve A' y = F to  ||F - A' y|| <= max(rtol ||F||, atol)  measured on the TRUE residual: BiCGStab's
 // recursive residual is only trusted to stop an inner run; each run is followed by one explicit
 // residual, and the correction equation is solved again if the target was missed.
-static int krylov_solve(Ctx* c, int* its, int* converged, double* relres, bool first_of_step = true) {
+static int krylov_solve(Ctx* c, int* its, int* converged, double* relres, bool first_of_step = true,
+                        double newton_floor = 0.0) {
     if (c->use_amg) {
         HIPCHK(amg_numeric_setup(c, *c->amg, first_of_step));   // Galerkin coarse operators of the Jacobian just assembled
     } else {
         HIPCHK(halo_exchange(c, c->d_dinv));  // ghost columns of A' = A D^-1 need their owners' diagonal
         launch_scale(c);
     }
-    const double rtol = c->params.krylov_rtol, atol = c->params.krylov_atol;
+    // newton_floor: absolute residual below which more digits cannot change Newton's own stopping decision
+    // (shk_newton_solve); the solve's target is max(rtol ||F||, atol, newton_floor)
+    const double rtol = c->params.krylov_rtol, atol = std::max(c->params.krylov_atol, newton_floor);
     int total = 0, conv = 0;
     double target = 0.0, rhs_norm = 0.0, rt = 0.0, rt_prev = 0.0;
     const int max_outer = 12;
@@ -732,7 +737,13 @@ int shk_newton_solve(shk_ctx* ctx, double dt, shk_solve_info* info) {
     while (!conv && it < c->params.newton_max_it) {
         int k = 0, kc = 0;
         double rr = 0.0;
-        if (krylov_solve(c, &k, &kc, &rr, it == 0)) return -1;
+        // Newton stops at ||F|| < max(atol, rtol ||F_0||) (DOLFINx defaults, solvers.py:52).  A linear residual a factor
+        // krylov_newton_eta (0.1) below that threshold cannot change that decision any more, so later Newton iterations
+        // -- whose right-hand side is already ~1e-5 ||F_0|| -- are not driven ten digits below their own ||F|| (the first
+        // iteration is unaffected: 0.1 x 1e-9 ||F_0|| = krylov_rtol ||F_0||).  Newton counts stay those of the LU oracle
+        // in every parity test; 0 restores the pure relative rule.
+        const double newton_target = std::max(c->params.newton_atol, c->params.newton_rtol * I.residual0);
+        if (krylov_solve(c, &k, &kc, &rr, it == 0, c->params.krylov_newton_eta * newton_target)) return -1;
         I.krylov_its += k;
         // a solve that stagnated between krylov_rtol and krylov_fail_rtol sits on its fp64 floor
         // eps || |J| |dx| || (Newton absorbs it); beyond that -- max_it, breakdown, divergence -- it has failed
