@@ -1059,7 +1059,7 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
             // do: the last two read the ghost values those exchanges left behind (lagged, still a fixed linear
             // operator) -- rehearsed with 4 subdomains at 1M rows: 57 -> 54 iterations per Newton iteration with
             // two exchanging levels, 51 -> 38 with all (one subdomain: 40), at no extra message.
-            const bool more = H.coarse4;
+            const bool more = H.coarse4 && (int)l >= H.coarse4_from;
             const float lw1 = more ? (float)(H.c4[0] / l4) : w1;
             const float lw2 = more ? (float)(H.c4[1] / l4) : w2;
             if (fused) {

@@ -224,6 +224,7 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
     }
     if (const char* sa = getenv("SHK_AMG_ALPHA")) H.alpha = atof(sa);
     if (const char* sa = getenv("SHK_AMG_COARSE4")) H.coarse4 = atoi(sa) != 0;
+    if (const char* sa = getenv("SHK_AMG_COARSE4_FROM")) H.coarse4_from = std::max(1, atoi(sa));
     if (const char* sa = getenv("SHK_AMG_DENSE_PERIOD")) H.dense_period = std::max(1, atoi(sa));
     {   // cycle doubling at the first sparse level of at most SHK_AMG_W_ROWS rows (experiment; default 0 = V-cycle:
         // measured at 10M | 1M rows it saves 4 | 10 % of the iterations and costs 5 | 44 % more time per step)

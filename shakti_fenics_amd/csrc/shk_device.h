@@ -358,6 +358,7 @@ struct AmgHierarchy {
     // [0.2, 0.8] 223 | 41.5, [0.25, 0.9] 225 | 41.7; [0.15, 0.8] and [0.25, 0.7] diverge at 10M rows (SHK_AMG_COARSE4=0)
     size_t w_level = 0;          // level whose cycle runs twice per visit (0: plain V-cycle); set at upload
     bool coarse4 = true;
+    int coarse4_from = 1;        // first level that runs the four-sweep sequence (levels above it: the finest level's two)
     bool top_four = false;       // the top level is itself a coarse level of a larger cycle (replicated hierarchy)
     double c4[4] = {1.143, 3.640, 1.430, 2.219};
     int64_t ap_nnz0 = 0;             // stored entries of the finest level's A*P operator
