@@ -7,7 +7,7 @@ import numpy as np
 
 from . import _lib
 from .bc import locate_boundary_dofs
-from .mesh import rectangle_mesh
+from .mesh import basin_mesh, rectangle_mesh
 from .synthetic import CONFIGS, N_BDRY, outflow_predicate, synthetic_fields
 
 
@@ -58,10 +58,12 @@ def _pmc_traffic(config, nv):
 
 class SingleRunner:
     def __init__(self, config="c4_10m", order="morton", dt=3600.0, storage=False, moulins=0, device=0,
-                 krylov_rtol=1e-10, shape=None, precond="amg"):
+                 krylov_rtol=1e-10, shape=None, precond="amg", basin=0):
         nx, ny, Lx, Ly = CONFIGS[config] if shape is None else shape
-        self.config_name = config if shape is None else None
-        self.dom = rectangle_mesh(nx, ny, Lx, Ly, order=order)
+        self.config_name = config if shape is None and not basin else None
+        # basin=n: the unstructured Delaunay basin mesh of ~n vertices (mesh.basin_mesh) instead of the rectangle
+        self.dom = basin_mesh(basin, order="random") if basin else rectangle_mesh(nx, ny, Lx, Ly, order=order)
+        self._outflow = (lambda X: X[0] < 1e-9) if basin else outflow_predicate(self.dom)
         self.dt = dt
         sf = synthetic_fields(self.dom, storage_on=storage, moulins=moulins)
         self.ctx = _lib.ShaktiHip(self.dom.xy, self.dom.cells, device=device)
@@ -74,15 +76,16 @@ class SingleRunner:
         c.set_field("b", np.abs(sf["b_init"]))
         c.set_field("N_n", sf["N_init"]); c.set_field("N", sf["N_init"])  # initial guess, solvers.py:48
         c.set_field("q", sf["q_init"]); c.set_field("melt_n", np.zeros(self.dom.num_vertices))
-        self.bc = locate_boundary_dofs(self.dom, outflow_predicate(self.dom))
+        self.bc = locate_boundary_dofs(self.dom, self._outflow)
         c.set_dirichlet(self.bc, N_BDRY)
         self.transport = "none"
         st = c.plan_stats()
         self.nv_global, self.ne_global, self.nnz_global = st["nv"], st["ne"], st["nnz"]
         self.stats = st
-        self._desc = (f"{Lx/1e3:.0f} km x {Ly/1e3:.0f} km rectangle, {nx}x{ny} jittered P1 mesh ({order} order), "
-                      f"dt {dt:g} s (first step 0.1 dt), storage {'on' if storage else 'off'}, {moulins} moulins, "
-                      f"Dirichlet N = {N_BDRY:g} Pa on x = 0")
+        mesh_txt = (f"Delaunay basin mesh of {self.dom.num_vertices} vertices (hole, curved outlet, random order)" if basin else
+                    f"{Lx/1e3:.0f} km x {Ly/1e3:.0f} km rectangle, {nx}x{ny} jittered P1 mesh ({order} order)")
+        self._desc = (f"{mesh_txt}, dt {dt:g} s (first step 0.1 dt), storage {'on' if storage else 'off'}, {moulins} moulins, "
+                      f"Dirichlet N = {N_BDRY:g} Pa on x = 0; |b_init| for the reference's signed draw (DESIGN.md section 1)")
         self.next_step = 0
 
     def describe(self):
@@ -194,15 +197,15 @@ class PartitionedRunner(SingleRunner):
     the global synthetic mesh, keeps its subdomain and joins the communicator."""
 
     def __init__(self, rank, world, device, config="c4_10m", order="morton", dt=3600.0, storage=False,
-                 moulins=0, krylov_rtol=1e-10, shape=None, transport="rccl", group=None, precond="amg"):
+                 moulins=0, krylov_rtol=1e-10, shape=None, transport="rccl", group=None, precond="amg", basin=0):
         from .distributed import make_context
         from .partition import partition
 
         nx, ny, Lx, Ly = CONFIGS[config] if shape is None else shape
-        dom = rectangle_mesh(nx, ny, Lx, Ly, order=order)
+        dom = basin_mesh(basin, order="random") if basin else rectangle_mesh(nx, ny, Lx, Ly, order=order)
         self.dt = dt
         sf = synthetic_fields(dom, storage_on=storage, moulins=moulins)
-        bc_global = locate_boundary_dofs(dom, outflow_predicate(dom))
+        bc_global = locate_boundary_dofs(dom, (lambda X: X[0] < 1e-9) if basin else outflow_predicate(dom))
         self.sub = sub = partition(dom, world, rank)
         self.nv_global, self.ne_global = dom.num_vertices, dom.num_cells
         g = sub.gid
@@ -228,9 +231,11 @@ class PartitionedRunner(SingleRunner):
         dist.all_reduce(t, group=group)
         self.nnz_global = int(t.item())
         self.transport = transport
-        self._desc = (f"{Lx/1e3:.0f} km x {Ly/1e3:.0f} km rectangle, {nx}x{ny} jittered P1 mesh ({order} order), "
-                      f"dt {dt:g} s (first step 0.1 dt), storage {'on' if storage else 'off'}, {moulins} moulins, "
-                      f"Dirichlet N = {N_BDRY:g} Pa on x = 0; {world} subdomains (RCB), {transport} halo")
+        mesh_txt = (f"Delaunay basin mesh of {dom.num_vertices} vertices (hole, curved outlet, random order)" if basin else
+                    f"{Lx/1e3:.0f} km x {Ly/1e3:.0f} km rectangle, {nx}x{ny} jittered P1 mesh ({order} order)")
+        self._desc = (f"{mesh_txt}, dt {dt:g} s (first step 0.1 dt), storage {'on' if storage else 'off'}, {moulins} moulins, "
+                      f"Dirichlet N = {N_BDRY:g} Pa on x = 0; |b_init| for the reference's signed draw; {world} subdomains (RCB), "
+                      f"{transport} halo")
         self.next_step = 0
         del dom, sf
 

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--precond", default="jacobi")
     ap.add_argument("--lx", type=float, default=20e3)
     ap.add_argument("--ly", type=float, default=10e3)
+    ap.add_argument("--basin", type=int, default=0, help="unstructured Delaunay basin mesh of about this many vertices")
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -41,7 +42,8 @@ def main():
     from shakti_fenics_amd.runner import PartitionedRunner, SingleRunner
 
     shape = (a.nx, a.ny, a.lx, a.ly)
-    run = PartitionedRunner(rank, world, dev, shape=shape, storage=True, transport=a.transport, precond=a.precond)
+    run = PartitionedRunner(rank, world, dev, shape=shape, storage=True, transport=a.transport, precond=a.precond,
+                            basin=a.basin)
     infos = []
     for i in range(a.steps):
         info = run.step(i)
@@ -55,7 +57,7 @@ def main():
     ok = True
     report = {"world": world, "transport": a.transport, "infos": infos}
     if rank == 0:
-        ref = SingleRunner(shape=shape, storage=True, device=dev, precond=a.precond)
+        ref = SingleRunner(shape=shape, storage=True, device=dev, precond=a.precond, basin=a.basin)
         ref_infos = []
         for i in range(a.steps):
             info = ref.step(i)

@@ -117,3 +117,22 @@ def test_restart_on_a_mesh_with_a_large_dense_level_agrees_to_solver_tolerance(t
         assert np.array_equal(got[:3], full[k][:3])                       # frames written before the interruption
         assert rel_l2(got[-1], full[k][-1]) < 1e-8, k
     assert np.array_equal(np.load(f"{md3.results_name}/newton_its.npy"), full["newton_its"])
+
+
+def test_editing_params_py_changes_the_solve(tmp_path, monkeypatch):
+    """The reference's users change physics by editing params.py (`from params import rho_i, rho_w, g`); the constants
+    of shakti_fenics_amd/params.py are what the library computes with (solvers._configure)."""
+    from shakti_fenics_amd import params as P
+    from shakti_fenics_amd.setups import setup_synthetic_cooke2 as S
+    from shakti_fenics_amd.solvers import get_bcs
+    monkeypatch.setattr(P, "A", 5.0e-24)
+    monkeypatch.setattr(P, "omega", 3.0e-3)
+    md = S.initialize(SerialComm(), nx=31, ny=31, days=4.0 / 24.0, results_root=tmp_path)
+    md.solve()
+    (dofs, val), = get_bcs(md)
+    fo, log = O.run(md.domain.xy, md.domain.cells, _oracle_fields(md), md.timesteps, O.Params(A=5.0e-24, omega=3.0e-3), dofs, val,
+                    nsteps=md.timesteps.size)
+    N = np.load(f"{md.results_name}/N.npy")
+    assert rel_l2(N[-1], fo.N) < 1e-7
+    f2, _ = O.run(md.domain.xy, md.domain.cells, _oracle_fields(md), md.timesteps, O.Params(), dofs, val, nsteps=md.timesteps.size)
+    assert rel_l2(N[-1], f2.N) > 1e-4            # the default constants give a visibly different answer

@@ -69,6 +69,16 @@ def test_partitioned_matches_single_at_1m_dof_four_subdomains():
 
 
 @pytest.mark.parametrize("precond", ["amg", "jacobi"])
+def test_partitioned_matches_single_on_the_unstructured_basin_mesh(precond):
+    """Recursive bisection of the Delaunay basin mesh (hole, curved outlet, valence-13 vertices, random vertex order):
+    irregular neighbour sets and halo lists, the distributed hierarchy on irregular aggregates; three subdomains."""
+    r = _launch(3, "gloo", 29585 if precond == "amg" else 29586, ("--precond", precond, "--basin", "30000"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    rep = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert rep["ok"] and rep["ghost_mismatch"] == 0.0 and max(rep["errs"].values()) < 1e-7
+
+
+@pytest.mark.parametrize("precond", ["amg", "jacobi"])
 def test_md_solve_on_two_ranks_writes_the_same_files_as_on_one(tmp_path, precond):
     """`torch.distributed.run --nproc-per-node 2 ... setup.initialize(TorchComm()); md.solve()`: partition, per-rank
     upload, gathers of the result rows and the results directory guard of solvers.solve's multi-rank branch."""

@@ -185,6 +185,37 @@ def test_blocked_dense_inverse_equals_the_pivotwise_one(hip):
     assert rel_l2(out["0"][1], out["1"][1]) < 1e-8
 
 
+def test_other_physical_constants_and_glen_exponent(hip):
+    """Constants other than params.py's defaults reach the kernels, and a non-cubic Glen exponent (constitutive.py:31
+    with n != 3: |N|^(n-1) through pow, every term on the degree-7 rule, the generic kernel instance) matches the oracle
+    through assembly, a Newton solve and the explicit updates."""
+    dom, f, bc, g = make_case(nx=37, ny=29, perturb=True)
+    kw = dict(n=2.5, A=1.0e-21, omega=2e-3, nu=1.5e-6, Lh=3.0e5, rho_i=910.0, rho_w=1020.0, g=9.8, b_min=2e-5)
+    prm = O.Params(**kw)
+    ctx = hip.ShaktiHip(dom.xy, dom.cells)
+    ctx.set_params(precond=hip.PRECOND["amg"], **kw)
+    upload(ctx, f, bc, g)
+    ctx.assemble(DT)
+    Fo, Jo = O.assemble(dom.xy, dom.cells, f, DT, prm, bc, g)
+    rp, ci, va = ctx.csr()
+    J = sp.csr_matrix((va, ci, rp), shape=Jo.shape)
+    assert rel_l2(ctx.residual(), Fo) < 1e-11 and abs(J - Jo).max() / abs(Jo).max() < 1e-12
+    # a solve from the unperturbed state
+    dom, f, bc, g = make_case(nx=37, ny=29)
+    upload(ctx, f, bc, g)
+    fo = f.copy()
+    info = ctx.newton_solve(0.1 * DT)
+    n_o, conv_o, _ = O.newton_solve(dom.xy, dom.cells, fo, 0.1 * DT, prm, bc, g)
+    assert info.converged and conv_o and info.newton_its == n_o
+    assert rel_l2(ctx.get_field("N"), fo.N) < 1e-8
+    ctx.set_field("N", fo.N)
+    ctx.update_explicit(0.1 * DT)
+    O.update_explicit(dom.xy, dom.cells, fo, 0.1 * DT, prm)
+    assert rel_l2(ctx.get_field("b"), fo.b) < 1e-12 and rel_l2(ctx.get_field("q"), fo.q) < 1e-12
+    assert ctx.get_field("b").min() >= 2e-5
+    ctx.close()
+
+
 def test_errors_are_loud(hip):
     dom, f, bc, g = make_case()
     ctx = hip.ShaktiHip(dom.xy, dom.cells)

@@ -6,16 +6,16 @@ import sys
 import numpy as np
 import pytest
 
-from shakti_fenics_amd.mesh import rectangle_mesh
+from shakti_fenics_amd.mesh import basin_mesh, rectangle_mesh
 from shakti_fenics_amd.partition import build_subdomain, rcb_partition
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("nparts", [1, 2, 3, 8])
-@pytest.mark.parametrize("order", ["morton", "random"])
+@pytest.mark.parametrize("order", ["morton", "random", "basin"])
 def test_partition_and_halo_plan(nparts, order):
-    dom = rectangle_mesh(40, 17, 100e3, 20e3, order=order)
+    dom = basin_mesh(3000) if order == "basin" else rectangle_mesh(40, 17, 100e3, 20e3, order=order)
     owner = rcb_partition(dom.xy, nparts)
     counts = np.bincount(owner, minlength=nparts)
     assert counts.sum() == dom.num_vertices and counts.max() - counts.min() <= nparts
