@@ -435,7 +435,6 @@ int shk_set_params(shk_ctx* ctx, const shk_params* p) {
     c->params = *p;
     c->use_amg = H != nullptr;
     c->amg = H;
-    c->amg_stale = true;   // the next linear solve refreshes the hierarchy whatever its place in a Newton loop
     derive_params(c);
     c->assembled = false;
     return 0;
@@ -639,15 +638,9 @@ static int read_aux_norm(Ctx* c, double* out) {  // fixed-order host sum of the 
 static int krylov_solve(Ctx* c, int* its, int* converged, double* relres, bool first_of_step = true,
                         double newton_floor = 0.0) {
     if (c->use_amg) {
-        // Galerkin coarse operators (and the float copy) of the Jacobian just assembled -- for the first Newton system of
-        // a solve.  Later Newton iterations of the same solve keep that preconditioner: between them the Jacobian changes
-        // only through the creep term (the one nonlinearity in N, solvers.py:35-45), the Krylov operator itself is always
-        // the fresh double-precision matrix, and the true-residual test certifies the result whatever M is.  Saves the
-        // ~1.9 ms refresh per further iteration at 10M DOF (SHK_AMG_REFRESH_ALWAYS=1 restores round 1's behaviour).
-        static const bool always = getenv("SHK_AMG_REFRESH_ALWAYS") && atoi(getenv("SHK_AMG_REFRESH_ALWAYS")) != 0;
-        if (first_of_step || always || c->amg_stale)
-            HIPCHK(amg_numeric_setup(c, *c->amg, first_of_step));
-        c->amg_stale = false;
+        // Galerkin coarse operators (and the float copy) of the Jacobian just assembled.  (Keeping the first Newton system's
+        // hierarchy for the later iterations of a solve was measured: 96.6 ms per step either way at 10M DOF -- not kept.)
+        HIPCHK(amg_numeric_setup(c, *c->amg, first_of_step));
     } else {
         HIPCHK(halo_exchange(c, c->d_dinv));  // ghost columns of A' = A D^-1 need their owners' diagonal
         launch_scale(c);

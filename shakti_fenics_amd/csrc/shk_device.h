@@ -457,7 +457,6 @@ struct Ctx {
     AmgHierarchy* amg = nullptr;    // the active one when use_amg
     float *d_phat = nullptr, *d_shat = nullptr;   // M^-1 p, M^-1 s: float, like everything the cycle produces
     bool use_amg = false;
-    bool amg_stale = true;      // hierarchy values do not belong to this context's current configuration yet
     double* d_part = nullptr;  // 8 arrays of kMaxParts: this subdomain's partial sums
     double* d_red = nullptr;   // what the consumers read: d_part itself (one context), or P_COUNT scalars = this
                                // subdomain's partial arrays summed in a fixed order, then all-reduced (48 B per
