@@ -222,7 +222,12 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
     const int nrows = r1 - r0;
 
     // ---- phase 0: stage plan slices, quadrature tables and the fields of the block's vertices ----
+    // the cells' vertex ids are requested with the fields (they depend on the descriptor only), not after the barrier
     const ushort4* __restrict__ cellv = reinterpret_cast<const ushort4*>(a.blk_cellv) + c0;
+    ushort4 cvw[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        cvw[r] = (!(a.ablate & 8) && tid + r * T < ncell) ? cellv[tid + r * T] : make_ushort4(0, 0, 0, 0);
     for (int i = tid; i <= ns; i += T) sp[i] = a.A.ptr[s0 + i];
     for (int i = tid; i <= nrows; i += T) ip[i] = a.incptr[r0 + i];
     for (int i = tid; i < ninc; i += T) ic[i] = a.inccode[ip0 + i];
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
     for (int r = 0; r < R; ++r) {
         const int t = tid + r * T;
         if (t < ncell) {
-            const ushort4 cv = cellv[t];
+            const ushort4 cv = (a.ablate & 8) ? cellv[t] : cvw[r];
             if (a.ablate & 1) {
 #pragma unroll
                 for (int k = 0; k < 9; ++k) out[r].K[k] = fld[cv.x] + k;
@@ -303,6 +308,19 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
     __syncthreads();
     auto tensor = [&](int k, int cell) -> double { return et[k * E + cell]; };
 
+    // ---- phase 2b: one thread per owned residual row (first: it needs LDS only, while the plan words of phase 2a
+    //      are still in flight) ----
+    for (int i = tid; i < nrows; i += T) {
+        const int v = r0 + i;
+        double sum = 0.0;
+        const int kb = ip[i] - ip0, ke = ip[i + 1] - ip0;
+        for (int q = kb; q < ke; ++q) {
+            const int code = ic[q];
+            sum += tensor(9 + (code & 3), code >> 2);
+        }
+        if (bcf[i]) sum = a.fld[0][v] - a.bc_value;  // set_bc(b, bcs, x, -1): F = N - g
+        a.F[v] = sum;
+    }
     // ---- phase 2a: one thread per SELL slot of the owned slices ----
     if (!(a.ablate & 2)) {
         // first slot of the block's 2nd .. 4th slice (INT_MAX when absent): a slot's slice by three compares
@@ -336,18 +354,6 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
             if (k == 0 && v < a.A.n_rows) a.dinv[v] = (sum != 0.0) ? 1.0 / sum : 1.0;  // the diagonal is stored first
             a.vals[s] = sum;  // padding slots hold exact zeros
         }
-    }
-    // ---- phase 2b: one thread per owned residual row ----
-    for (int i = tid; i < nrows; i += T) {
-        const int v = r0 + i;
-        double sum = 0.0;
-        const int kb = ip[i] - ip0, ke = ip[i + 1] - ip0;
-        for (int q = kb; q < ke; ++q) {
-            const int code = ic[q];
-            sum += tensor(9 + (code & 3), code >> 2);
-        }
-        if (bcf[i]) sum = a.fld[0][v] - a.bc_value;  // set_bc(b, bcs, x, -1): F = N - g
-        a.F[v] = sum;
     }
 }
 
