@@ -124,6 +124,29 @@ def test_ten_steps_match_oracle(hip, precond):
     ctx.close()
 
 
+def test_hundred_steps_do_not_drift_from_the_lu_oracle(hip):
+    """The linear solves stop a factor 10 below Newton's own threshold (shk_params.krylov_newton_eta), the oracle solves
+    every system exactly (LU): over 100 time steps with storage and two moulins the two trajectories stay together to
+    1e-7 and Newton needs the same iterations (2-5 per step on this 100 km box) at every step."""
+    dom, f, bc, g = make_case(nx=45, ny=45, Lx=100e3, Ly=100e3, moulins=2)
+    ctx = hip.ShaktiHip(dom.xy, dom.cells)
+    ctx.set_params(precond=hip.PRECOND["amg"])
+    assert ctx.get_params().krylov_newton_eta == 0.1
+    upload(ctx, f, bc, g)
+    ts = np.arange(101) * DT
+    fo, log = O.run(dom.xy, dom.cells, f.copy(), ts, O.Params(), bc, g, nsteps=100)
+    its = []
+    for i in range(100):
+        info = ctx.step(0.1 * DT if i == 0 else DT)
+        assert info.converged and not info.krylov_failed
+        its.append(info.newton_its)
+    assert its == [l["niter"] for l in log]
+    assert rel_l2(ctx.get_field("N"), fo.N) < 1e-7
+    assert rel_l2(ctx.get_field("b"), fo.b) < 1e-7
+    assert rel_l2(ctx.get_field("q"), fo.q) < 1e-6
+    ctx.close()
+
+
 def test_three_steps_at_62k_dof_match_oracle(hip):
     """The largest size the LU oracle finishes in seconds (the mesh of bench.py's cpu_baseline leg, 560 x 112 on the
     100 km x 20 km geometry, with the lake storage term and 12 moulins): a multigrid hierarchy of four levels, the
