@@ -133,6 +133,9 @@ typedef int (*shk_exchange_fn)(void* user, int32_t n_nbr, const int32_t* nbr, co
 typedef int (*shk_allreduce_fn)(void* user, double* buf, int64_t n);
 int shk_comm_init_callbacks(shk_ctx* ctx, int32_t rank, int32_t nranks, shk_exchange_fn exchange,
                             shk_allreduce_fn allreduce, void* user);
+/* Loop-back test of the RCCL call sequence of the data path on this context's communicator (grouped ncclSend /
+ * ncclRecv to the rank itself, ncclAllReduce, async-error query, all on the context's stream); 0 = passed. */
+int shk_comm_selftest(shk_ctx* ctx);
 /* Message rounds this context has issued since creation: n[0] ghost exchanges, n[1] all-reduces, n[2] bytes sent in
  * exchanges, n[3] bytes all-reduced (per rank).  Differences around a solve give rounds per Krylov iteration. */
 int shk_comm_stats(shk_ctx* ctx, int64_t n[4]);

@@ -49,7 +49,7 @@ EXPORTS = (
     "shk_assemble", "shk_get_residual", "shk_csr_nnz", "shk_get_csr", "shk_linear_solve", "shk_spmv",
     "shk_newton_solve", "shk_update_explicit", "shk_step", "shk_sync", "shk_profile_enable",
     "shk_profile_read", "shk_time_kernel", "shk_plan_stats", "shk_set_halo", "shk_comm_unique_id",
-    "shk_comm_init_rccl", "shk_comm_init_callbacks", "shk_comm_stats", "shk_halo_update", "shk_interp_regular_grid",
+    "shk_comm_init_rccl", "shk_comm_init_callbacks", "shk_comm_selftest", "shk_comm_stats", "shk_halo_update", "shk_interp_regular_grid",
     "shk_points_in_polygon",
 )
 
@@ -105,6 +105,7 @@ def load():
         "shk_comm_init_callbacks": ([vp, i32, i32, EXCHANGE_FN, ALLREDUCE_FN, vp], C.c_int),
         "shk_halo_update": ([vp, i32], C.c_int),
         "shk_comm_stats": ([vp, P(i64)], C.c_int),
+        "shk_comm_selftest": ([vp], C.c_int),
         "shk_interp_regular_grid": ([C.c_int, i64, vp, vp, i64, i64, vp, vp, vp, i32, vp], C.c_int),
         "shk_points_in_polygon": ([C.c_int, i64, vp, vp, i64, vp, vp], C.c_int),
     }
@@ -345,6 +346,9 @@ class ShaktiHip:
 
         self._cb = (EXCHANGE_FN(_ex), ALLREDUCE_FN(_ar))  # keep the thunks alive
         self._check(self.lib.shk_comm_init_callbacks(self._h, rank, nranks, self._cb[0], self._cb[1], None))
+
+    def comm_selftest(self):
+        self._check(self.lib.shk_comm_selftest(self._h))
 
     def comm_stats(self) -> dict:
         n = (C.c_int64 * 4)()

@@ -880,6 +880,14 @@ int shk_comm_init_callbacks(shk_ctx* ctx, int32_t rank, int32_t nranks, shk_exch
     return 0;
 }
 
+int shk_comm_selftest(shk_ctx* ctx) {
+    CHECK_CTX(ctx);
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    HIPCHK(hipSetDevice(c->device));
+    if (const char* e = rccl_selftest(c)) return fail(std::string("RCCL self-test: ") + e);
+    return 0;
+}
+
 int shk_comm_stats(shk_ctx* ctx, int64_t n[4]) {
     CHECK_CTX(ctx);
     if (!n) return fail("null output");

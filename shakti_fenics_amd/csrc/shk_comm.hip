@@ -80,6 +80,42 @@ const char* rccl_init(Ctx* c, int rank, int nranks, const void* id128) {
     return nullptr;
 }
 
+// Loop-back self-test of the RCCL call sequence the data path uses (grouped ncclSend / ncclRecv on the context's
+// stream, ncclAllReduce, the async-error query): on a one-rank communicator the peer is the rank itself.  The one-GPU
+// boxes this was built on cannot host two RCCL ranks, so this is the only way those calls ever executed there.
+const char* rccl_selftest(Ctx* c) {
+    if (c->comm.kind != Comm::RCCL || !c->comm.nccl) return "no RCCL communicator on this context";
+    ncclComm_t comm = reinterpret_cast<ncclComm_t>(c->comm.nccl);
+    const int n = 1000, me = c->comm.rank;
+    std::vector<double> h(n), back(2 * n + 4, 0.0);
+    for (int i = 0; i < n; ++i) h[i] = 0.5 + i;
+    double* d = nullptr;
+    if (hipMalloc((void**)&d, (2 * n + 4) * sizeof(double)) != hipSuccess) return "hipMalloc failed";
+    const char* err = nullptr;
+    do {
+        if (hipMemcpyAsync(d, h.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) { err = "H2D failed"; break; }
+        if (hipMemsetAsync(d + n, 0, (n + 4) * sizeof(double), c->stream) != hipSuccess) { err = "memset failed"; break; }
+        g_rccl.GroupStart();
+        ncclResult_t r1 = g_rccl.Send(d, n, ncclDouble, me, comm, c->stream);
+        ncclResult_t r2 = g_rccl.Recv(d + n, n, ncclDouble, me, comm, c->stream);
+        ncclResult_t r3 = g_rccl.GroupEnd();
+        if (r1 != ncclSuccess || r2 != ncclSuccess || r3 != ncclSuccess) { err = "grouped ncclSend / ncclRecv failed"; break; }
+        if (g_rccl.AllReduce(d, d + 2 * n, 4, ncclDouble, ncclSum, comm, c->stream) != ncclSuccess) { err = "ncclAllReduce failed"; break; }
+        if (g_rccl.CommGetAsyncError) {
+            ncclResult_t ae = ncclSuccess;
+            if (g_rccl.CommGetAsyncError(comm, &ae) != ncclSuccess || (ae != ncclSuccess && ae != ncclInProgress)) { err = "asynchronous RCCL error"; break; }
+        }
+        if (hipMemcpyAsync(back.data(), d, (2 * n + 4) * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) { err = "D2H failed"; break; }
+        if (hipStreamSynchronize(c->stream) != hipSuccess) { err = "stream synchronisation failed"; break; }
+        for (int i = 0; i < n && !err; ++i)
+            if (back[n + i] != h[i]) err = "ncclRecv delivered other values than ncclSend sent";
+        for (int i = 0; i < 4 && !err; ++i)
+            if (back[2 * n + i] != c->comm.nranks * h[i] && c->comm.nranks == 1) err = "ncclAllReduce returned a wrong sum";
+    } while (false);
+    (void)hipFree(d);
+    return err;
+}
+
 void comm_destroy(Ctx* c) {
     if (c->comm.kind == Comm::RCCL && c->comm.nccl && g_rccl.CommDestroy)
         g_rccl.CommDestroy(reinterpret_cast<ncclComm_t>(c->comm.nccl));

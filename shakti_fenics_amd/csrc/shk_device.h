@@ -520,6 +520,7 @@ const char* rccl_load();
 int rccl_unique_id(void* out128);
 const char* rccl_init(Ctx* c, int rank, int nranks, const void* id128);
 void comm_destroy(Ctx* c);
+const char* rccl_selftest(Ctx* c);
 hipError_t halo_exchange(Ctx* c, double* vec);                       // level 0
 hipError_t halo_exchange_plan(Ctx* c, const HaloPlan& P, double* vec);
 hipError_t halo_exchange_plan_f32(Ctx* c, const HaloPlan& P, float* vec);

@@ -105,6 +105,15 @@ def test_rccl_two_rank_parity():
     assert rep["ok"] and rep["ghost_mismatch"] == 0.0 and max(rep["errs"].values()) < 1e-7
 
 
+def test_rccl_loopback_selftest_of_the_data_path_calls():
+    """The grouped ncclSend / ncclRecv, ncclAllReduce and async-error calls of csrc/shk_comm.hip, executed for real: a
+    one-rank communicator exchanging with itself (the closest a one-GPU box gets to the multi-rank data path)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_selftest_worker.py")], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL_SELFTEST_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_rccl_single_rank_communicator():
     r = _launch(1, "rccl", 29521)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
