@@ -134,11 +134,18 @@ typedef int (*shk_allreduce_fn)(void* user, double* buf, int64_t n);
 int shk_comm_init_callbacks(shk_ctx* ctx, int32_t rank, int32_t nranks, shk_exchange_fn exchange,
                             shk_allreduce_fn allreduce, void* user);
 /* Loop-back test of the RCCL call sequence of the data path on this context's communicator (grouped ncclSend /
- * ncclRecv to the rank itself, ncclAllReduce, async-error query, all on the context's stream); 0 = passed. */
+ * ncclRecv to the rank itself on the context's stream and again on a second, event-ordered stream, ncclAllReduce,
+ * async-error query); 0 = passed. */
 int shk_comm_selftest(shk_ctx* ctx);
 /* Message rounds this context has issued since creation: n[0] ghost exchanges, n[1] all-reduces, n[2] bytes sent in
  * exchanges, n[3] bytes all-reduced (per rank).  Differences around a solve give rounds per Krylov iteration. */
 int shk_comm_stats(shk_ctx* ctx, int64_t n[4]);
+/* Interior / boundary split of the finest level's sweeps (several subdomains; default on with RCCL, off with the
+ * host-staged callbacks, SHK_OVERLAP=0/1 overrides): the ghost
+ * exchange of the two Krylov products and of the finest smoothing sweep travels on a second stream while the SELL
+ * slices without ghost columns are swept; the others follow once it has arrived.  n[0] 1 = active, n[1] slices that
+ * read ghost columns, n[2] all slices of the subdomain, n[3] exchanges issued this way since creation. */
+int shk_comm_overlap(shk_ctx* ctx, int64_t n[4]);
 /* Refresh the ghost entries of a field from their owners (scatter_forward, solvers.py:197,229). */
 int shk_halo_update(shk_ctx* ctx, int32_t field);
 

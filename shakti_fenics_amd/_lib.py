@@ -49,7 +49,7 @@ EXPORTS = (
     "shk_assemble", "shk_get_residual", "shk_csr_nnz", "shk_get_csr", "shk_linear_solve", "shk_spmv",
     "shk_newton_solve", "shk_update_explicit", "shk_step", "shk_sync", "shk_profile_enable",
     "shk_profile_read", "shk_time_kernel", "shk_plan_stats", "shk_set_halo", "shk_comm_unique_id",
-    "shk_comm_init_rccl", "shk_comm_init_callbacks", "shk_comm_selftest", "shk_comm_stats", "shk_halo_update", "shk_interp_regular_grid",
+    "shk_comm_init_rccl", "shk_comm_init_callbacks", "shk_comm_selftest", "shk_comm_stats", "shk_comm_overlap", "shk_halo_update", "shk_interp_regular_grid",
     "shk_points_in_polygon",
 )
 
@@ -105,6 +105,7 @@ def load():
         "shk_comm_init_callbacks": ([vp, i32, i32, EXCHANGE_FN, ALLREDUCE_FN, vp], C.c_int),
         "shk_halo_update": ([vp, i32], C.c_int),
         "shk_comm_stats": ([vp, P(i64)], C.c_int),
+        "shk_comm_overlap": ([vp, P(i64)], C.c_int),
         "shk_comm_selftest": ([vp], C.c_int),
         "shk_interp_regular_grid": ([C.c_int, i64, vp, vp, i64, i64, vp, vp, vp, i32, vp], C.c_int),
         "shk_points_in_polygon": ([C.c_int, i64, vp, vp, i64, vp, vp], C.c_int),
@@ -354,6 +355,12 @@ class ShaktiHip:
         n = (C.c_int64 * 4)()
         self._check(self.lib.shk_comm_stats(self._h, n))
         return dict(exchanges=int(n[0]), allreduces=int(n[1]), bytes_exchanged=int(n[2]), bytes_allreduced=int(n[3]))
+
+    def comm_overlap(self) -> dict:
+        """Interior / boundary split of the finest level's sweeps (several subdomains): see shk_comm_overlap."""
+        n = (C.c_int64 * 4)()
+        self._check(self.lib.shk_comm_overlap(self._h, n))
+        return dict(active=bool(n[0]), boundary_slices=int(n[1]), slices=int(n[2]), overlapped_exchanges=int(n[3]))
 
     def halo_update(self, name: str):
         self._check(self.lib.shk_halo_update(self._h, FIELDS[name]))

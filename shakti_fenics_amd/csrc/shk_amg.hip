@@ -288,19 +288,29 @@ struct AmgSmoothArgs {
     TO* xo;                 // smoothed iterate
     float omega;
     const int* done;        // Krylov stop flag: once set, every later kernel of the queue returns at once
+    SplitSell split;        // PASS 1, 2 only (finest level of a decomposed mesh)
 };
 // FINE only gives the finest level its own symbol, so that profilers report its launches separately
-template <bool FINE, class TX, class TR, class TO>
+template <bool FINE, class TX, class TR, class TO, int PASS = 0>   // PASS: SplitSell (shk_device.h)
 __global__ __launch_bounds__(kBlock) void k_amg_post(const AmgSmoothArgs<TX, TR, TO> a) {
     if (*a.done) return;
     const int lane = threadIdx.x & 63;
-    for (SliceLoop it(a.A, wave_index()); it.valid(); it.next()) {
-        const int row = min(it.s * kSlice + lane, a.A.n_rows - 1);   // tail rows of the last slice: clamped, not stored
+    auto slice = [&](int s, const SellMeta& m) {
+        const int row = min(s * kSlice + lane, a.A.n_rows - 1);   // tail rows of the last slice: clamped, not stored
         const TX xr = a.x[row];            // the row's own entries are requested ahead of the slice stream
         const TR rr = a.r[row];
         const float di = a.dinv[row];
-        const auto sum = sell_row_sum(a.A, it.m, a.vals, a.x, lane);
-        if (it.s * kSlice + lane < a.A.n_rows) a.xo[row] = (TO)(xr + a.omega * di * (rr - sum));
+        const bool skip = PASS == 1 ? a.split.ghost[s] != 0 : false;
+        const auto sum = sell_row_sum(a.A, m, a.vals, a.x, lane);
+        if (s * kSlice + lane < a.A.n_rows && !skip) a.xo[row] = (TO)(xr + a.omega * di * (rr - sum));
+    };
+    if (PASS == 2) {
+        for (int k = 4 * blockIdx.x + wave_index(); k < a.split.n_list; k += 4 * gridDim.x) {
+            const int s = __builtin_amdgcn_readfirstlane(a.split.list[k]);
+            slice(s, sell_meta(a.A, s));
+        }
+    } else {
+        for (SliceLoop it(a.A, wave_index()); it.valid(); it.next()) slice(it.s, it.m);
     }
 }
 
@@ -919,6 +929,26 @@ static void launch_post(Ctx* c, const DevSell& A, const float* vals, const float
     else hipLaunchKernelGGL((k_amg_post<FINE, TX, TR, TO>), g, dim3(kBlock), 0, c->stream, a);
 }
 
+// The finest level's sweep on a decomposed mesh, overlapped with the ghost update of its input (Ctx::overlap): the
+// slices without ghost columns are swept while the exchange travels on comm_stream, the others after it has arrived.
+static hipError_t launch_post_split(Ctx* c, const DevSell& A, const float* vals, const float* dinv, const double* r,
+                                    float* x, float* xo, float w, const int* done) {
+    AmgSmoothArgs<float, double, float> a{A, vals, dinv, r, x, xo, w, done,
+                                          SplitSell{c->d_slice_ghost, c->d_bslices, c->n_bslices}};
+    hipError_t e;
+    if ((e = hipEventRecord(c->ev_ready, c->stream)) != hipSuccess) return e;
+    launch_phase(c, SHK_PH_AMG_FINE, k_amg_post<true, float, double, float, 1>, dim3(std::min((A.nslice + 3) / 4, 2048)),
+                 dim3(kBlock), 0, a);
+    if ((e = halo_begin_f32(c, x)) != hipSuccess) return e;
+    if ((e = halo_end(c)) != hipSuccess) return e;
+    if (c->n_bslices > 0) {
+        PhaseTimer t(c, SHK_PH_HALO);
+        hipLaunchKernelGGL((k_amg_post<true, float, double, float, 2>), dim3(std::min((c->n_bslices + 3) / 4, 2048)),
+                           dim3(kBlock), 0, c->stream, a);
+    }
+    return hipSuccess;
+}
+
 // z = M^-1 r : one V(0,2) cycle.  r and z have the fine level's length; r is not modified.
 hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
     const int32_t n_top = H.topA.n_rows, ncol_top = H.topA.n_cols;
@@ -1046,8 +1076,12 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
                 if (halo && (e = halo_exchange_plan_f32(c, *HP, zout)) != hipSuccess) return e;
                 launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)zout, H.x0, omega, done);
             }
-            if (halo && (e = halo_exchange_plan_f32(c, *HP, H.x0)) != hipSuccess) return e;
-            launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)H.x0, zout, w2, done);
+            if (halo && c->overlap && H.plan_of[0] == 0 && A.ptr == c->d_sell_ptr) {
+                if ((e = launch_post_split(c, A, H.top_vals, H.top_dinv, rin, H.x0, zout, w2, done)) != hipSuccess) return e;
+            } else {
+                if (halo && (e = halo_exchange_plan_f32(c, *HP, H.x0)) != hipSuccess) return e;
+                launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)H.x0, zout, w2, done);
+            }
             if (four) {
                 launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)zout, H.x0, (float)(H.c4[2] / l4), done);
                 launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)H.x0, zout, (float)(H.c4[3] / l4), done);

@@ -394,12 +394,16 @@ int shk_destroy(shk_ctx* ctx) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
     comm_destroy(c);
     if (c->comm.h_send) (void)hipHostFree(c->comm.h_send);
     if (c->comm.h_recv) (void)hipHostFree(c->comm.h_recv);
     if (c->comm.h_red) (void)hipHostFree(c->comm.h_red);
     for (auto& ev : c->ev_pool) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     for (hipEvent_t ev : c->poll_ev) if (ev) (void)hipEventDestroy(ev);
+    if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+    if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+    if (c->ev_halo) (void)hipEventDestroy(c->ev_halo);
     for (void* p : c->allocs) (void)hipFree(p);
     if (c->h_state) (void)hipHostFree(c->h_state);
     if (c->h_part) (void)hipHostFree(c->h_part);
@@ -829,7 +833,33 @@ int shk_set_halo(shk_ctx* ctx, int32_t n_nbr, const int32_t* nbr_rank, const int
     return 0;
 }
 
-static int comm_common(Ctx* c, int rank, int nranks) {
+// Interior / boundary split of the level-0 sweeps (SplitSell): flag the SELL slices that store a ghost column --
+// padding entries included, whatever column they carry -- and create the stream the exchanges travel on.
+static hipError_t overlap_setup(Ctx* c) {
+    const SellPattern& A = c->plan.A;
+    std::vector<uint8_t> flag((size_t)std::max(A.nslice, 1), 0);
+    std::vector<int32_t> list;
+    for (int32_t s = 0; s < A.nslice; ++s) {
+        bool ghost = false;
+        for (int32_t k = A.ptr[s]; k < A.ptr[s + 1] && !ghost; ++k) ghost = A.col[k] >= c->n_own;
+        if (A.cbase[s] >= 0)
+            for (int32_t k = A.ptr16[s]; k < A.ptr16[s + 1] && !ghost; ++k) ghost = A.cbase[s] + (int32_t)A.col16[k] >= c->n_own;
+        if (ghost) { flag[s] = 1; list.push_back(s); }
+    }
+    hipError_t e;
+    if ((e = upload(c, &c->d_slice_ghost, flag)) != hipSuccess) return e;
+    if ((e = upload(c, &c->d_bslices, list)) != hipSuccess) return e;
+    c->n_bslices = (int)list.size();
+    if ((e = dev_alloc(c, &c->d_part_b, (size_t)P_COUNT * kMaxParts)) != hipSuccess) return e;
+    if ((e = hipMemset(c->d_part_b, 0, (size_t)P_COUNT * kMaxParts * sizeof(double))) != hipSuccess) return e;
+    if ((e = hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking)) != hipSuccess) return e;
+    if ((e = hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming)) != hipSuccess) return e;
+    if ((e = hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming)) != hipSuccess) return e;
+    c->overlap = true;
+    return hipSuccess;
+}
+
+static int comm_common(Ctx* c, int rank, int nranks, bool overlap_default) {
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail("bad rank / nranks");
     if (c->comm.plans.empty()) return fail("call shk_set_halo before initialising the communicator");
     for (int r : c->comm.plans[0].nbr)
@@ -842,6 +872,12 @@ static int comm_common(Ctx* c, int rank, int nranks) {
         c->np = 1;           // every subdomain reads the same all-reduced scalars
         c->red_stride = 1;
     }
+    // Interior / boundary overlap of the finest level's exchanges: on for RCCL, off for the host-staged transport, whose
+    // callback blocks the host anyway (measured with 2 subdomains sharing one GPU at 1M rows: 133 -> 183 ms per step
+    // with it; the hand-over to a second stream and back costs ~15 us, tools/probe_stream_handoff.py).  SHK_OVERLAP=0/1
+    // overrides either way.
+    const bool want_overlap = getenv("SHK_OVERLAP") ? atoi(getenv("SHK_OVERLAP")) != 0 : overlap_default;
+    if (nranks > 1 && want_overlap && !c->overlap) HIPCHK(overlap_setup(c));
     c->comm.rank = rank;
     c->comm.nranks = nranks;
     return 0;
@@ -861,7 +897,7 @@ int shk_comm_init_rccl(shk_ctx* ctx, int32_t rank, int32_t nranks, const void* i
     if (c->comm.kind != Comm::NONE) return fail("communicator already initialised");
     HIPCHK(hipSetDevice(c->device));
     if (const char* e = rccl_load()) return fail(e);
-    if (comm_common(c, rank, nranks)) return -1;
+    if (comm_common(c, rank, nranks, true)) return -1;
     if (const char* e = rccl_init(c, rank, nranks, id128)) return fail(std::string("ncclCommInitRank: ") + e);
     return 0;
 }
@@ -872,7 +908,7 @@ int shk_comm_init_callbacks(shk_ctx* ctx, int32_t rank, int32_t nranks, shk_exch
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!exchange || !allreduce) return fail("null callback");
     if (c->comm.kind != Comm::NONE) return fail("communicator already initialised");
-    if (comm_common(c, rank, nranks)) return -1;
+    if (comm_common(c, rank, nranks, false)) return -1;
     c->comm.cb_exchange = exchange;
     c->comm.cb_allreduce = allreduce;
     c->comm.cb_user = user;
@@ -893,6 +929,14 @@ int shk_comm_stats(shk_ctx* ctx, int64_t n[4]) {
     if (!n) return fail("null output");
     const Comm& m = reinterpret_cast<Ctx*>(ctx)->comm;
     n[0] = m.n_exchange; n[1] = m.n_allreduce; n[2] = m.bytes_exchange; n[3] = m.bytes_allreduce;
+    return 0;
+}
+
+int shk_comm_overlap(shk_ctx* ctx, int64_t n[4]) {
+    CHECK_CTX(ctx);
+    if (!n) return fail("null output");
+    const Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    n[0] = c->overlap ? 1 : 0; n[1] = c->n_bslices; n[2] = c->plan.A.nslice; n[3] = c->comm.n_overlapped;
     return 0;
 }
 

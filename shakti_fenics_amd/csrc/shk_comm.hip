@@ -81,37 +81,56 @@ const char* rccl_init(Ctx* c, int rank, int nranks, const void* id128) {
 }
 
 // Loop-back self-test of the RCCL call sequence the data path uses (grouped ncclSend / ncclRecv on the context's
-// stream, ncclAllReduce, the async-error query): on a one-rank communicator the peer is the rank itself.  The one-GPU
-// boxes this was built on cannot host two RCCL ranks, so this is the only way those calls ever executed there.
+// stream, the same again on a second stream ordered by events -- the overlapped exchange of halo_begin / halo_end --,
+// ncclAllReduce, the async-error query): on a one-rank communicator the peer is the rank itself.  The one-GPU boxes
+// this was built on cannot host two RCCL ranks, so this is the only way those calls ever executed there.
 const char* rccl_selftest(Ctx* c) {
     if (c->comm.kind != Comm::RCCL || !c->comm.nccl) return "no RCCL communicator on this context";
     ncclComm_t comm = reinterpret_cast<ncclComm_t>(c->comm.nccl);
     const int n = 1000, me = c->comm.rank;
-    std::vector<double> h(n), back(2 * n + 4, 0.0);
+    std::vector<double> h(n), back(3 * n + 4, 0.0);
     for (int i = 0; i < n; ++i) h[i] = 0.5 + i;
     double* d = nullptr;
-    if (hipMalloc((void**)&d, (2 * n + 4) * sizeof(double)) != hipSuccess) return "hipMalloc failed";
+    if (hipMalloc((void**)&d, (3 * n + 4) * sizeof(double)) != hipSuccess) return "hipMalloc failed";
+    hipStream_t side = nullptr;
+    hipEvent_t ready = nullptr, arrived = nullptr;
     const char* err = nullptr;
     do {
+        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ready, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&arrived, hipEventDisableTiming) != hipSuccess) { err = "second stream / events"; break; }
         if (hipMemcpyAsync(d, h.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) { err = "H2D failed"; break; }
-        if (hipMemsetAsync(d + n, 0, (n + 4) * sizeof(double), c->stream) != hipSuccess) { err = "memset failed"; break; }
+        if (hipMemsetAsync(d + n, 0, (2 * n + 4) * sizeof(double), c->stream) != hipSuccess) { err = "memset failed"; break; }
         g_rccl.GroupStart();
         ncclResult_t r1 = g_rccl.Send(d, n, ncclDouble, me, comm, c->stream);
         ncclResult_t r2 = g_rccl.Recv(d + n, n, ncclDouble, me, comm, c->stream);
         ncclResult_t r3 = g_rccl.GroupEnd();
         if (r1 != ncclSuccess || r2 != ncclSuccess || r3 != ncclSuccess) { err = "grouped ncclSend / ncclRecv failed"; break; }
-        if (g_rccl.AllReduce(d, d + 2 * n, 4, ncclDouble, ncclSum, comm, c->stream) != ncclSuccess) { err = "ncclAllReduce failed"; break; }
+        // second round on the side stream: forwards what the first round delivered
+        if (hipEventRecord(ready, c->stream) != hipSuccess || hipStreamWaitEvent(side, ready, 0) != hipSuccess) { err = "event ordering failed"; break; }
+        g_rccl.GroupStart();
+        r1 = g_rccl.Send(d + n, n, ncclDouble, me, comm, side);
+        r2 = g_rccl.Recv(d + 2 * n, n, ncclDouble, me, comm, side);
+        r3 = g_rccl.GroupEnd();
+        if (r1 != ncclSuccess || r2 != ncclSuccess || r3 != ncclSuccess) { err = "grouped ncclSend / ncclRecv on the second stream failed"; break; }
+        if (hipEventRecord(arrived, side) != hipSuccess || hipStreamWaitEvent(c->stream, arrived, 0) != hipSuccess) { err = "event ordering failed"; break; }
+        if (g_rccl.AllReduce(d + 2 * n, d + 3 * n, 4, ncclDouble, ncclSum, comm, c->stream) != ncclSuccess) { err = "ncclAllReduce failed"; break; }
         if (g_rccl.CommGetAsyncError) {
             ncclResult_t ae = ncclSuccess;
             if (g_rccl.CommGetAsyncError(comm, &ae) != ncclSuccess || (ae != ncclSuccess && ae != ncclInProgress)) { err = "asynchronous RCCL error"; break; }
         }
-        if (hipMemcpyAsync(back.data(), d, (2 * n + 4) * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) { err = "D2H failed"; break; }
+        if (hipMemcpyAsync(back.data(), d, (3 * n + 4) * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) { err = "D2H failed"; break; }
         if (hipStreamSynchronize(c->stream) != hipSuccess) { err = "stream synchronisation failed"; break; }
         for (int i = 0; i < n && !err; ++i)
             if (back[n + i] != h[i]) err = "ncclRecv delivered other values than ncclSend sent";
+        for (int i = 0; i < n && !err; ++i)
+            if (back[2 * n + i] != h[i]) err = "the exchange on the second stream delivered other values than the first round left";
         for (int i = 0; i < 4 && !err; ++i)
-            if (back[2 * n + i] != c->comm.nranks * h[i] && c->comm.nranks == 1) err = "ncclAllReduce returned a wrong sum";
+            if (back[3 * n + i] != c->comm.nranks * h[i] && c->comm.nranks == 1) err = "ncclAllReduce returned a wrong sum";
     } while (false);
+    if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
+    if (ready) (void)hipEventDestroy(ready);
+    if (arrived) (void)hipEventDestroy(arrived);
     (void)hipFree(d);
     return err;
 }
@@ -136,7 +155,7 @@ __global__ __launch_bounds__(kBlock) void k_unpack_f32(int64_t n, const double* 
 }
 
 // Send the packed buffer, receive the neighbours' into `recv` (device memory, neighbour-major).
-static hipError_t exchange_packed(Ctx* c, const HaloPlan& P, double* recv) {
+static hipError_t exchange_packed(Ctx* c, const HaloPlan& P, double* recv, hipStream_t stream) {
     Comm& m = c->comm;
     const int64_t nsend = P.send_ptr.back(), nrecv = P.recv_ptr.back();
     m.n_exchange += 1;
@@ -146,8 +165,8 @@ static hipError_t exchange_packed(Ctx* c, const HaloPlan& P, double* recv) {
         g_rccl.GroupStart();
         for (size_t k = 0; k < P.nbr.size(); ++k) {
             const int64_t ns = P.send_ptr[k + 1] - P.send_ptr[k], nr = P.recv_ptr[k + 1] - P.recv_ptr[k];
-            if (ns > 0) g_rccl.Send(m.d_sendbuf + P.send_ptr[k], (size_t)ns, ncclDouble, P.nbr[k], comm, c->stream);
-            if (nr > 0) g_rccl.Recv(recv + P.recv_ptr[k], (size_t)nr, ncclDouble, P.nbr[k], comm, c->stream);
+            if (ns > 0) g_rccl.Send(m.d_sendbuf + P.send_ptr[k], (size_t)ns, ncclDouble, P.nbr[k], comm, stream);
+            if (nr > 0) g_rccl.Recv(recv + P.recv_ptr[k], (size_t)nr, ncclDouble, P.nbr[k], comm, stream);
         }
         ncclResult_t r = g_rccl.GroupEnd();
         if (r == ncclSuccess && g_rccl.CommGetAsyncError) {   // a transport failure must not surface later as a hung solve
@@ -159,50 +178,78 @@ static hipError_t exchange_packed(Ctx* c, const HaloPlan& P, double* recv) {
     // CALLBACK: host-staged
     hipError_t e = hipSuccess;
     if (nsend > 0)
-        e = hipMemcpyAsync(m.h_send, m.d_sendbuf, (size_t)nsend * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        e = hipMemcpyAsync(m.h_send, m.d_sendbuf, (size_t)nsend * sizeof(double), hipMemcpyDeviceToHost, stream);
     if (e != hipSuccess) return e;
-    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
     std::vector<int32_t> nb(P.nbr.begin(), P.nbr.end());
     if (m.cb_exchange(m.cb_user, (int32_t)nb.size(), nb.data(), m.h_send, P.send_ptr.data(), m.h_recv,
                       P.recv_ptr.data()) != 0)
         return hipErrorUnknown;
     if (nrecv > 0)
-        e = hipMemcpyAsync(recv, m.h_recv, (size_t)nrecv * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        e = hipMemcpyAsync(recv, m.h_recv, (size_t)nrecv * sizeof(double), hipMemcpyHostToDevice, stream);
     return e;
 }
 
 // Fill the ghost segment of `vec` (a vector of the level that `P` belongs to) with the owners' current values.
-hipError_t halo_exchange_plan(Ctx* c, const HaloPlan& P, double* vec) {
+static hipError_t exchange_f64(Ctx* c, const HaloPlan& P, double* vec, hipStream_t stream) {
     Comm& m = c->comm;
-    if (m.kind == Comm::NONE || m.nranks <= 1 || P.nbr.empty()) return hipSuccess;
-    PhaseTimer t(c, SHK_PH_HALO);
     const int64_t nsend = P.send_ptr.back();
     if (nsend > 0) {
         const int g = (int)std::min<int64_t>((nsend + kBlock - 1) / kBlock, 1024);
-        hipLaunchKernelGGL(k_pack<double>, dim3(g), dim3(kBlock), 0, c->stream, nsend, P.d_send_idx, vec, m.d_sendbuf);
+        hipLaunchKernelGGL(k_pack<double>, dim3(g), dim3(kBlock), 0, stream, nsend, P.d_send_idx, vec, m.d_sendbuf);
     }
-    return exchange_packed(c, P, vec + P.n_own);
+    return exchange_packed(c, P, vec + P.n_own, stream);
 }
-
 // The same for a float vector of the multigrid preconditioner: values travel as doubles (the volume is a few
 // thousand entries) and are narrowed again on arrival.
-hipError_t halo_exchange_plan_f32(Ctx* c, const HaloPlan& P, float* vec) {
+static hipError_t exchange_f32(Ctx* c, const HaloPlan& P, float* vec, hipStream_t stream) {
     Comm& m = c->comm;
-    if (m.kind == Comm::NONE || m.nranks <= 1 || P.nbr.empty()) return hipSuccess;
-    PhaseTimer t(c, SHK_PH_HALO);
     const int64_t nsend = P.send_ptr.back(), nrecv = P.recv_ptr.back();
     if (nsend > 0) {
         const int g = (int)std::min<int64_t>((nsend + kBlock - 1) / kBlock, 1024);
-        hipLaunchKernelGGL(k_pack<float>, dim3(g), dim3(kBlock), 0, c->stream, nsend, P.d_send_idx, vec, m.d_sendbuf);
+        hipLaunchKernelGGL(k_pack<float>, dim3(g), dim3(kBlock), 0, stream, nsend, P.d_send_idx, vec, m.d_sendbuf);
     }
-    hipError_t e = exchange_packed(c, P, m.d_recvbuf);
+    hipError_t e = exchange_packed(c, P, m.d_recvbuf, stream);
     if (e != hipSuccess) return e;
     if (nrecv > 0) {
         const int g = (int)std::min<int64_t>((nrecv + kBlock - 1) / kBlock, 1024);
-        hipLaunchKernelGGL(k_unpack_f32, dim3(g), dim3(kBlock), 0, c->stream, nrecv, m.d_recvbuf, vec + P.n_own);
+        hipLaunchKernelGGL(k_unpack_f32, dim3(g), dim3(kBlock), 0, stream, nrecv, m.d_recvbuf, vec + P.n_own);
     }
     return hipSuccess;
 }
+
+static bool no_exchange(const Ctx* c, const HaloPlan& P) {
+    return c->comm.kind == Comm::NONE || c->comm.nranks <= 1 || P.nbr.empty();
+}
+hipError_t halo_exchange_plan(Ctx* c, const HaloPlan& P, double* vec) {
+    if (no_exchange(c, P)) return hipSuccess;
+    PhaseTimer t(c, SHK_PH_HALO);
+    return exchange_f64(c, P, vec, c->stream);
+}
+hipError_t halo_exchange_plan_f32(Ctx* c, const HaloPlan& P, float* vec) {
+    if (no_exchange(c, P)) return hipSuccess;
+    PhaseTimer t(c, SHK_PH_HALO);
+    return exchange_f32(c, P, vec, c->stream);
+}
+
+// Overlapped level-0 exchange (Ctx::overlap): the caller has recorded ev_ready behind the kernel that completed `vec`
+// and has launched its interior pass; pack, transport and unpack run on comm_stream, ev_halo marks their end.
+template <class T>
+static hipError_t halo_begin_t(Ctx* c, T* vec) {
+    const HaloPlan& P = c->comm.plans[0];
+    hipError_t e;
+    if ((e = hipStreamWaitEvent(c->comm_stream, c->ev_ready, 0)) != hipSuccess) return e;
+    if (!no_exchange(c, P)) {
+        c->comm.n_overlapped += 1;
+        if constexpr (sizeof(T) == sizeof(double)) e = exchange_f64(c, P, vec, c->comm_stream);
+        else e = exchange_f32(c, P, vec, c->comm_stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipEventRecord(c->ev_halo, c->comm_stream);
+}
+hipError_t halo_begin(Ctx* c, double* vec) { return halo_begin_t(c, vec); }
+hipError_t halo_begin_f32(Ctx* c, float* vec) { return halo_begin_t(c, vec); }
+hipError_t halo_end(Ctx* c) { return hipStreamWaitEvent(c->stream, c->ev_halo, 0); }
 
 hipError_t halo_exchange(Ctx* c, double* vec) {
     if (c->comm.plans.empty()) return hipSuccess;
@@ -237,12 +284,18 @@ hipError_t allreduce_buffer(Ctx* c, const double* src, double* dst, size_t n) {
     return hipMemcpyAsync(dst, m.h_red, n * sizeof(double), hipMemcpyHostToDevice, c->stream);
 }
 
-// One workgroup per reduction slot: this subdomain's partial array summed in a fixed order.
-__global__ __launch_bounds__(kBlock) void k_reduce_parts(int n, const double* __restrict__ part, double* __restrict__ out) {
+// One workgroup per reduction slot: this subdomain's partial array summed in a fixed order (then, when the products
+// ran in two passes, the boundary pass's array behind it).
+__global__ __launch_bounds__(kBlock) void k_reduce_parts(int n, const double* __restrict__ part, int nb,
+                                                         const double* __restrict__ part_b, double* __restrict__ out) {
     __shared__ double sh[4];
     const double* p = part + (size_t)blockIdx.x * kMaxParts;
     double a = 0.0;
     for (int i = threadIdx.x; i < n; i += kBlock) a += p[i];
+    if (nb > 0) {
+        const double* q = part_b + (size_t)blockIdx.x * kMaxParts;
+        for (int i = threadIdx.x; i < nb; i += kBlock) a += q[i];
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
@@ -255,8 +308,10 @@ __global__ __launch_bounds__(kBlock) void k_reduce_parts(int n, const double* __
 // ends up with the same bits, so all take identical decisions.
 hipError_t allreduce_parts(Ctx* c, int first, int nslots) {
     if (c->comm.kind == Comm::NONE || c->comm.nranks <= 1) return hipSuccess;
+    const int nb = c->overlap ? std::min((c->n_bslices + 3) / 4, kMaxParts) : 0;   // grid of launch_spmv_boundary
     hipLaunchKernelGGL(k_reduce_parts, dim3(nslots), dim3(kBlock), 0, c->stream, c->grid,
-                       c->d_part + (size_t)first * kMaxParts, c->d_red + first);
+                       c->d_part + (size_t)first * kMaxParts, nb, nb > 0 ? c->d_part_b + (size_t)first * kMaxParts : nullptr,
+                       c->d_red + first);
     return allreduce_buffer(c, c->d_red + first, c->d_red + first, (size_t)nslots);
 }
 

@@ -192,6 +192,17 @@ struct SliceLoop {
     }
 };
 
+// Interior / boundary passes of a level-0 sweep over a decomposed mesh.  PASS 0: every slice (one subdomain, or no
+// overlap).  PASS 1 ("interior"): the ordinary sweep, but slices flagged in `ghost` keep their hands off the output
+// (their row sums, computed from ghost values that may be arriving at that moment, are dropped: ~3 % redundant
+// reads instead of a second slice order).  PASS 2 ("boundary"): only the flagged slices, from the list, after the
+// receive has completed.
+struct SplitSell {
+    const uint8_t* ghost;    // nslice flags (PASS 1)
+    const int32_t* list;     // flagged slices (PASS 2)
+    int32_t n_list;
+};
+
 // Multigrid down-sweep over four levels in one launch (k_amg_restrict4).  An aligned group of 256 rows holds
 // complete aggregate trees four levels deep (256 = 4^4): one workgroup pass leaves the right-hand sides of
 // levels 1 .. nlev behind, through LDS, instead of one launch per level.  Tables are indexed by the coarse row's
@@ -406,6 +417,7 @@ struct Comm {
     void* cb_user = nullptr;
     std::vector<HaloPlan> plans;             // [0] fine level, [l] multigrid level l (distributed hierarchy)
     int64_t n_exchange = 0, n_allreduce = 0, bytes_exchange = 0, bytes_allreduce = 0;   // message rounds since creation
+    int64_t n_overlapped = 0;                // of n_exchange: issued on comm_stream behind an interior pass
     double* d_sendbuf = nullptr;             // sized for plans[0], the largest
     double* d_recvbuf = nullptr;             // staging of a float vector's ghosts (they travel as doubles)
     double *h_send = nullptr, *h_recv = nullptr, *h_red = nullptr;  // pinned staging (CALLBACK)
@@ -465,6 +477,15 @@ struct Ctx {
     KrylovState* h_state = nullptr;  // pinned, 2 slots
     double* h_part = nullptr;        // pinned, kMaxParts
     hipEvent_t poll_ev[3] = {nullptr, nullptr, nullptr};   // [0,1] stop-flag polls, [2] deadline waits
+    // Interior / boundary split of the level-0 sweeps (several subdomains only, SplitSell below): the ghost exchange
+    // runs on comm_stream while the main stream sweeps the slices that read no ghost column.
+    bool overlap = false;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_halo = nullptr;   // vector complete (main) / ghosts arrived (comm_stream)
+    uint8_t* d_slice_ghost = nullptr;   // nslice: 1 = the slice stores a ghost column
+    int32_t* d_bslices = nullptr;       // those slices, ascending
+    int n_bslices = 0;
+    double* d_part_b = nullptr;         // P_COUNT arrays of kMaxParts: partial sums of the boundary passes
     bool assembled = false;
     double assembled_dt = 0.0;
     // profiling
@@ -524,6 +545,12 @@ const char* rccl_selftest(Ctx* c);
 hipError_t halo_exchange(Ctx* c, double* vec);                       // level 0
 hipError_t halo_exchange_plan(Ctx* c, const HaloPlan& P, double* vec);
 hipError_t halo_exchange_plan_f32(Ctx* c, const HaloPlan& P, float* vec);
+// Overlapped form of the two level-0 exchanges: halo_begin* enqueues pack + exchange on comm_stream behind everything
+// the main stream holds so far; the caller then launches its interior pass and calls halo_end, which makes the main
+// stream wait for the ghosts.  (The host-staged transport blocks inside halo_begin*: launch the interior pass first.)
+hipError_t halo_begin(Ctx* c, double* vec);
+hipError_t halo_begin_f32(Ctx* c, float* vec);
+hipError_t halo_end(Ctx* c);
 hipError_t allreduce_buffer(Ctx* c, const double* src, double* dst, size_t n);  // element-wise sum over subdomains
 int amg_setup_distributed(Ctx* c, std::string& err);  // collective
 hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense, bool decided = false);

@@ -81,9 +81,10 @@ struct SpmvArgs {
     const double* sdot;      // MODE 2: the vector s of (t . s) (== x unless a preconditioner sits in between)
     double* part;            // partial arrays (MODE 1, 2)
     KrylovState* st;
+    SplitSell split;         // PASS 1, 2 only
 };
 
-template <int MODE, class TX>
+template <int MODE, class TX, int PASS = 0>   // PASS: SplitSell (shk_device.h)
 __global__ __launch_bounds__(kBlock) void k_spmv(const SpmvArgs a) {
     __shared__ double sh4[4];
     const int tid = threadIdx.x;
@@ -92,17 +93,27 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const SpmvArgs a) {
     }
     const int lane = tid & 63;
     double d0 = 0.0, d1 = 0.0, d2 = 0.0;
-    for (SliceLoop it(a.A, wave_index()); it.valid(); it.next()) {
-        const int row = min(it.s * kSlice + lane, a.A.n_rows - 1);   // tail rows of the last slice: clamped, not used
+    auto slice = [&](int s, const SellMeta& m) {
+        const int row = min(s * kSlice + lane, a.A.n_rows - 1);   // tail rows of the last slice: clamped, not used
         // the dot-product operands are requested ahead of the slice stream
         const double rh = MODE != 0 ? a.rhat[row] : 0.0;
         const double sd = MODE == 2 ? a.sdot[row] : 0.0;
-        const double sum = sell_row_sum<12>(a.A, it.m, a.vals, reinterpret_cast<const TX*>(a.x), lane);
-        if (it.s * kSlice + lane < a.A.n_rows) {
+        const bool skip = PASS == 1 ? a.split.ghost[s] != 0 : false;   // scalar load, needed only after the stream
+        const double sum = sell_row_sum<12>(a.A, m, a.vals, reinterpret_cast<const TX*>(a.x), lane);
+        if (s * kSlice + lane < a.A.n_rows && !skip) {
             a.y[row] = sum;
             if (MODE == 1) d0 += rh * sum;
             if (MODE == 2) { d0 += sum * sd; d1 += sum * sum; d2 += rh * sum; }
         }
+    };
+    if (PASS == 2) {
+        const int w = wave_index();
+        for (int k = 4 * blockIdx.x + w; k < a.split.n_list; k += 4 * gridDim.x) {
+            const int s = __builtin_amdgcn_readfirstlane(a.split.list[k]);
+            slice(s, sell_meta(a.A, s));
+        }
+    } else {
+        for (SliceLoop it(a.A, wave_index()); it.valid(); it.next()) slice(it.s, it.m);
     }
     if (MODE == 1) {
         d0 = block_sum(d0, sh4);
@@ -124,6 +135,7 @@ static SpmvArgs spmv_args(Ctx* c, const double* vals, const void* x, double* y) 
     SpmvArgs a;
     a.A = c->sell();
     a.vals = vals; a.x = x; a.y = y; a.rhat = c->d_rhat; a.sdot = nullptr; a.part = c->d_part; a.st = c->d_state;
+    a.split = SplitSell{c->d_slice_ghost, c->d_bslices, c->n_bslices};
     return a;
 }
 
@@ -300,14 +312,63 @@ void launch_accumulate(Ctx* c, bool first) {
     hipLaunchKernelGGL(k_accumulate, dim3(c->grid), dim3(kBlock), 0, c->stream, c->n_own, first ? 1 : 0, c->d_y,
                        c->d_ytot);
 }
+// Boundary pass of a split product: the flagged slices, after the ghosts have arrived.  Accounted to the halo
+// phase (it is the part of the product that had to wait for the exchange).
+template <int MODE, class TX>
+static void launch_spmv_boundary(Ctx* c, SpmvArgs a) {
+    if (c->n_bslices <= 0) return;
+    a.part = c->d_part_b;
+    PhaseTimer t(c, SHK_PH_HALO);
+    hipLaunchKernelGGL((k_spmv<MODE, TX, 2>), dim3(std::min((c->n_bslices + 3) / 4, kMaxParts)), dim3(kBlock), 0, c->stream, a);
+}
+
 hipError_t launch_true_residual(Ctx* c) {  // d_rhs = F - A' ytot, partials in P_AUX
-    hipError_t e = halo_exchange(c, c->d_ytot);
-    if (e != hipSuccess) return e;
-    launch_spmv_plain(c, c->use_amg ? c->d_vals : c->d_vals_s, c->d_ytot, c->d_t);
+    const double* A = c->use_amg ? c->d_vals : c->d_vals_s;
+    hipError_t e;
+    if (c->overlap) {
+        if ((e = hipEventRecord(c->ev_ready, c->stream)) != hipSuccess) return e;
+        const SpmvArgs a = spmv_args(c, A, c->d_ytot, c->d_t);
+        launch_phase(c, SHK_PH_SPMV, k_spmv<0, double, 1>, dim3(c->grid), dim3(kBlock), 0, a);
+        if ((e = halo_begin(c, c->d_ytot)) != hipSuccess) return e;
+        if ((e = halo_end(c)) != hipSuccess) return e;
+        launch_spmv_boundary<0, double>(c, a);
+    } else {
+        if ((e = halo_exchange(c, c->d_ytot)) != hipSuccess) return e;
+        launch_spmv_plain(c, A, c->d_ytot, c->d_t);
+    }
     PhaseTimer t(c, SHK_PH_VECTOR);
     hipLaunchKernelGGL(k_true_residual, dim3(c->grid), dim3(kBlock), 0, c->stream, c->n_own, c->d_F, c->d_t,
                        c->d_rhs, c->d_part + P_AUX * kMaxParts);
     return allreduce_parts(c, P_AUX, 1);
+}
+
+// One product of the Krylov loop, v = A' x (MODE 1) or t = A' x (MODE 2), with the ghost update of x it needs.
+// Several subdomains: the exchange travels on comm_stream while the slices without ghost columns are swept.
+template <int MODE>
+static hipError_t krylov_product(Ctx* c, const double* A, const void* x, double* y, const double* sdot) {
+    const dim3 g(c->grid), b(kBlock);
+    const bool amg = c->use_amg;
+    SpmvArgs a = spmv_args(c, A, x, y);
+    a.sdot = sdot;
+    hipError_t e;
+    if (c->overlap) {
+        if ((e = hipEventRecord(c->ev_ready, c->stream)) != hipSuccess) return e;
+        if (amg) launch_phase(c, SHK_PH_SPMV, k_spmv<MODE, float, 1>, g, b, 0, a);
+        else launch_phase(c, SHK_PH_SPMV, k_spmv<MODE, double, 1>, g, b, 0, a);
+        if ((e = amg ? halo_begin_f32(c, (float*)const_cast<void*>(x)) : halo_begin(c, (double*)const_cast<void*>(x))) != hipSuccess) return e;
+        if ((e = halo_end(c)) != hipSuccess) return e;
+        if (amg) launch_spmv_boundary<MODE, float>(c, a);
+        else launch_spmv_boundary<MODE, double>(c, a);
+        return hipSuccess;
+    }
+    if (amg) {
+        if (!c->comm.plans.empty() && (e = halo_exchange_plan_f32(c, c->comm.plans[0], (float*)const_cast<void*>(x))) != hipSuccess) return e;
+        launch_phase(c, SHK_PH_SPMV, k_spmv<MODE, float>, g, b, 0, a);
+    } else {
+        if ((e = halo_exchange(c, (double*)const_cast<void*>(x))) != hipSuccess) return e;
+        launch_phase(c, SHK_PH_SPMV, k_spmv<MODE, double>, g, b, 0, a);
+    }
+    return hipSuccess;
 }
 
 hipError_t krylov_iteration(Ctx* c, int it) {
@@ -318,28 +379,16 @@ hipError_t krylov_iteration(Ctx* c, int it) {
     // leaves M^-1 p, M^-1 s in float (the product and the solution update read them as such)
     const double* A = c->use_amg ? c->d_vals : c->d_vals_s;
     const bool amg = c->use_amg;
-    if (amg) {
-        if ((e = amg_vcycle(c, *c->amg, c->d_p, c->d_phat)) != hipSuccess) return e;
-        if (!c->comm.plans.empty() && (e = halo_exchange_plan_f32(c, c->comm.plans[0], c->d_phat)) != hipSuccess) return e;
-    } else if ((e = halo_exchange(c, c->d_p)) != hipSuccess) return e;
-    if (amg) launch_phase(c, SHK_PH_SPMV, k_spmv<1, float>, g, b, 0, spmv_args(c, A, c->d_phat, c->d_v));
-    else launch_phase(c, SHK_PH_SPMV, k_spmv<1, double>, g, b, 0, spmv_args(c, A, c->d_p, c->d_v));
+    if (amg && (e = amg_vcycle(c, *c->amg, c->d_p, c->d_phat)) != hipSuccess) return e;
+    if ((e = krylov_product<1>(c, A, amg ? (const void*)c->d_phat : (const void*)c->d_p, c->d_v, nullptr)) != hipSuccess) return e;
     if ((e = allreduce_parts(c, P_RR, 2)) != hipSuccess) return e;
     {
         PhaseTimer t(c, SHK_PH_VECTOR);
         hipLaunchKernelGGL(k_bicg_s, g, b, 0, c->stream, c->n_own, it, c->params.krylov_max_it, c->cur_rtol2,
                            c->cur_atol2, c->np, c->red_stride, c->d_red, part, c->d_r, c->d_v, c->d_rhat, c->d_s, c->d_state);
     }
-    if (amg) {
-        if ((e = amg_vcycle(c, *c->amg, c->d_s, c->d_shat)) != hipSuccess) return e;
-        if (!c->comm.plans.empty() && (e = halo_exchange_plan_f32(c, c->comm.plans[0], c->d_shat)) != hipSuccess) return e;
-    } else if ((e = halo_exchange(c, c->d_s)) != hipSuccess) return e;
-    {
-        SpmvArgs a = spmv_args(c, A, amg ? (const void*)c->d_shat : (const void*)c->d_s, c->d_t);
-        a.sdot = c->d_s;
-        if (amg) launch_phase(c, SHK_PH_SPMV, k_spmv<2, float>, g, b, 0, a);
-        else launch_phase(c, SHK_PH_SPMV, k_spmv<2, double>, g, b, 0, a);
-    }
+    if (amg && (e = amg_vcycle(c, *c->amg, c->d_s, c->d_shat)) != hipSuccess) return e;
+    if ((e = krylov_product<2>(c, A, amg ? (const void*)c->d_shat : (const void*)c->d_s, c->d_t, c->d_s)) != hipSuccess) return e;
     if ((e = allreduce_parts(c, P_TS, 4)) != hipSuccess) return e;
     {
         PhaseTimer t(c, SHK_PH_VECTOR);

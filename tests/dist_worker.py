@@ -55,7 +55,7 @@ def main():
     gathered = [None] * world if rank == 0 else None
     dist.gather_object((sub.gid[: sub.n_own], mine, sub.gid[sub.n_own:], ghost_N), gathered, dst=0)
     ok = True
-    report = {"world": world, "transport": a.transport, "infos": infos}
+    report = {"world": world, "transport": a.transport, "infos": infos, "overlap": run.ctx.comm_overlap()}
     if rank == 0:
         ref = SingleRunner(shape=shape, storage=True, device=dev, precond=a.precond, basin=a.basin)
         ref_infos = []
@@ -81,6 +81,13 @@ def main():
             # the distributed hierarchy keeps every cross-subdomain coupling (only the aggregates differ: they follow
             # each subdomain's own k-d order), so Krylov iteration counts must stay at the one-subdomain level
             ok = ok and all(x[1] <= 1.3 * y[1] + 3 for x, y in zip(infos, ref_infos))
+        ov = report["overlap"]
+        # default: on for RCCL, off for the host-staged transport; SHK_OVERLAP overrides
+        if world > 1 and os.environ.get("SHK_OVERLAP", "1" if a.transport == "rccl" else "0") != "0":
+            # the level-0 exchanges travelled on the second stream behind an interior pass, over a genuine split
+            ok = ok and ov["active"] and ov["overlapped_exchanges"] > 0 and 0 < ov["boundary_slices"] < ov["slices"]
+        else:
+            ok = ok and not ov["active"] and ov["overlapped_exchanges"] == 0
         report["ok"] = ok
         print(json.dumps(report), flush=True)
         if a.out:
