@@ -53,7 +53,9 @@ def parse():
     ap.add_argument("--transport", default="rccl", help="rccl (xGMI) | gloo (host-staged, tests)")
     ap.add_argument("--allow-host-staged", action="store_true",
                     help="if RCCL cannot be used, run the same solver over the host-staged gloo transport instead of failing")
-    ap.add_argument("--strict-steps", type=int, default=2, help="extra steps (after the timed region) with krylov_newton_eta = 0")
+    ap.add_argument("--strict-steps", type=int, default=2,
+                    help="extra steps (after the timed region) with krylov_newton_eta = 0 and krylov_warm_start = 0: round 1's rule")
+    ap.add_argument("--warm-start", type=int, default=4, help="shk_params.krylov_warm_start (0: every linear solve starts from zero)")
     ap.add_argument("--steady-max", type=int, default=50, help="N=1: total steps of the steady-state march after the timed "
                     "region (0: skip); stops early once ||dN||/||N|| < 1e-8")
     ap.add_argument("--precond", default="amg", help="amg (aggregation multigrid, default) | jacobi (north_star's solver; diverges at 10M DOF)")
@@ -178,6 +180,7 @@ def main():
 
     t_start = time.perf_counter()
     run = make_runner(args, rank, world, local_rank)
+    run.ctx.set_params(krylov_warm_start=args.warm_start)
     say(f"setup done: {run.describe()}")
 
     def barrier():
@@ -227,7 +230,11 @@ def main():
             "krylov_its_per_newton": krylov / max(newton, 1),
             "krylov": f"BiCGStab, right preconditioner {args.precond}; every linear solve runs until its TRUE residual is below "
                       f"max({args.krylov_rtol:g} ||F_k||, 0.1 x Newton's own stopping threshold max(1e-10, 1e-9 ||F_0||)) "
-                      "(shk_params.krylov_newton_eta; Newton counts equal the LU oracle's in every parity test)",
+                      "(shk_params.krylov_newton_eta); "
+                      + (f"the solve of Newton iteration k starts from the least-squares combination of the solutions of iteration k "
+                         f"of the previous {args.warm_start} steps (shk_params.krylov_warm_start) " if args.warm_start > 0
+                         else "every solve starts from zero ")
+                      + "-- Newton counts equal the LU oracle's in every parity test",
             "first_step": "0.1 dt (solvers.py:81); |b_init| instead of the reference's signed draw (DESIGN.md section 1)",
             "parallelism": f"dd{world}" if world > 1 else "single",
         },
@@ -242,9 +249,10 @@ def main():
                                  "note": "rounds rank 0 issued inside the timed region (Newton iterations' ghost updates, "
                                          "hierarchy refreshes and the replicated level's gathers included) per Krylov iteration"}
     if args.strict_steps > 0:
-        # the same workload continued with every linear solve driven to krylov_rtol ||F_k|| (krylov_newton_eta = 0): what
-        # the Newton-aware stopping floor saves, reported beside the headline, never instead of it
-        run.ctx.set_params(krylov_newton_eta=0.0)
+        # the same workload continued with every linear solve started from zero and driven to krylov_rtol ||F_k||
+        # (krylov_newton_eta = 0, krylov_warm_start = 0): what the Newton-aware stopping floor and the warm start save,
+        # reported beside the headline, never instead of it
+        run.ctx.set_params(krylov_newton_eta=0.0, krylov_warm_start=0)
         barrier()
         t1 = time.perf_counter()
         nn = kk = 0
@@ -254,11 +262,11 @@ def main():
             kk += info.krylov_its
         barrier()
         w = time.perf_counter() - t1
-        run.ctx.set_params(krylov_newton_eta=0.1)
+        run.ctx.set_params(krylov_newton_eta=0.1, krylov_warm_start=args.warm_start)
         out["strict_linear_solves"] = {"value": nv * nn / w if nn else 0.0, "unit": "DOF-updates/s", "steps": args.strict_steps,
                                        "ms_per_step": 1e3 * w / args.strict_steps, "newton_its": nn, "krylov_its": kk,
                                        "krylov_its_per_newton": kk / max(nn, 1),
-                                       "note": "krylov_newton_eta = 0: every linear solve to 1e-10 ||F_k||, as in round 1"}
+                                       "note": "krylov_newton_eta = 0, krylov_warm_start = 0: every linear solve from zero to 1e-10 ||F_k||, as in round 1"}
         say(f"strict leg done: {nn} newton, {kk} krylov, {w:.2f} s")
     if not args.no_roofline:
         roof = run.roofline(HBM_PEAK_GBS)  # one more (collective) step with per-launch hipEvents

@@ -48,6 +48,11 @@ typedef struct shk_params {
     int32_t krylov_check_every; /* iterations enqueued between host stop-flag polls; 0 = automatic */
     int32_t precond;            /* shk_precond; shk_default_params gives SHK_PC_JACOBI (north_star's solver), the Python
                                    mirror and bench.py select SHK_PC_AMG */
+    int32_t krylov_warm_start;  /* 0..4: inside shk_newton_solve the linear solve of Newton iteration k (k < 3) starts from
+                                   the least-squares combination of the solutions of iteration k of that many previous
+                                   steps (minimising ||F - J sum c_j g_j||: it can only lower the starting residual) instead
+                                   of zero.  The stopping rule (true residual against ||F_k||) is untouched.  Default 4;
+                                   0 = every solve starts from zero, as in round 1 */
 } shk_params;
 
 /* Right preconditioner of BiCGStab.  JACOBI is folded into the matrix (A D^-1).  AMG = one V(0,2) cycle (two

@@ -23,7 +23,7 @@ class shk_params(C.Structure):
     _fields_ = [(n, C.c_double) for n in
                 ("g", "rho_i", "rho_w", "nu", "Lh", "omega", "n", "A", "b_min",
                  "newton_rtol", "newton_atol", "newton_relax", "krylov_rtol", "krylov_atol", "krylov_fail_rtol", "krylov_newton_eta")] + \
-               [(n, C.c_int32) for n in ("newton_max_it", "krylov_max_it", "krylov_check_every", "precond")]
+               [(n, C.c_int32) for n in ("newton_max_it", "krylov_max_it", "krylov_check_every", "precond", "krylov_warm_start")]
 
 
 class shk_solve_info(C.Structure):

@@ -264,6 +264,7 @@ int shk_default_params(shk_params* p) {
     p->krylov_rtol = 1e-10; p->krylov_atol = 1e-50; p->krylov_max_it = 20000; p->krylov_check_every = 0;
     p->krylov_fail_rtol = 1e-6;
     p->krylov_newton_eta = 0.1;
+    p->krylov_warm_start = 4;
     p->precond = SHK_PC_JACOBI;
     return 0;
 }
@@ -308,6 +309,7 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
     c->cells_staged = (int64_t)P.blk_cells.size();
     c->grid = (int)std::min<int64_t>(kMaxParts, std::max<int64_t>(1, (c->n_own + kBlock - 1) / kBlock));
     c->np = c->grid;
+    if (const char* w = getenv("SHK_WARM_ITS")) c->warm_its = std::max(1, std::min(atoi(w), (int)Ctx::kWarmIts));   // experiments
     if (P.verts_max > kAsmVertsMax) { delete c; return fail("an assembly block touches more than 768 vertices (degenerate mesh?)"); }
     c->asm_lds = assemble_lds_bytes(P, &c->asm_region_a);
     if (c->asm_lds > 160 * 1024) { delete c; return fail("assembly LDS budget exceeds 160 KiB"); }
@@ -419,6 +421,7 @@ int shk_set_params(shk_ctx* ctx, const shk_params* p) {
     if (p->newton_max_it < 0 || p->krylov_max_it < 1 || p->krylov_check_every < 0) return fail("bad iteration limits");
     if (!(p->krylov_fail_rtol >= 0)) return fail("krylov_fail_rtol must be >= 0");
     if (!(p->krylov_newton_eta >= 0 && p->krylov_newton_eta <= 1)) return fail("krylov_newton_eta must be in [0, 1]");
+    if (p->krylov_warm_start < 0 || p->krylov_warm_start > Ctx::kWarmDepth) return fail("krylov_warm_start must be in 0..4");
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (p->precond != SHK_PC_JACOBI && p->precond != SHK_PC_AMG && p->precond != SHK_PC_AMG_LOCAL)
         return fail("unknown preconditioner id");
@@ -639,8 +642,24 @@ static int read_aux_norm(Ctx* c, double* out) {  // fixed-order host sum of the 
 // Solve A' y = F to  ||F - A' y|| <= max(rtol ||F||, atol)  measured on the TRUE residual: BiCGStab's
 // recursive residual is only trusted to stop an inner run; each run is followed by one explicit
 // residual, and the correction equation is solved again if the target was missed.
-static int krylov_solve(Ctx* c, int* its, int* converged, double* relres, bool first_of_step = true,
-                        double newton_floor = 0.0) {
+// Storage of the warm start (launch_warm_start), allocated when a solve first asks for it.
+static int warm_alloc(Ctx* c, int newton_it) {
+    if (!c->d_part_w) {
+        HIPCHK(dev_alloc(c, &c->d_part_w, (size_t)Ctx::kWarmDots * kMaxParts));
+        HIPCHK(hipMemset(c->d_part_w, 0, (size_t)Ctx::kWarmDots * kMaxParts * sizeof(double)));
+        HIPCHK(dev_alloc(c, &c->d_red_w, (size_t)Ctx::kWarmDots));
+    }
+    for (int j = 0; j < Ctx::kWarmDepth; ++j)
+        if (!c->d_guess[newton_it][j]) {
+            HIPCHK(dev_alloc(c, &c->d_guess[newton_it][j], (size_t)c->n_loc));
+            HIPCHK(hipMemset(c->d_guess[newton_it][j], 0, (size_t)c->n_loc * sizeof(double)));
+        }
+    return 0;
+}
+
+static int krylov_solve(Ctx* c, int* its, int* converged, double* relres, int newton_it = 0,
+                        double newton_floor = 0.0, double fnorm = -1.0) {
+    const bool first_of_step = newton_it == 0;
     if (c->use_amg) {
         // Galerkin coarse operators (and the float copy) of the Jacobian just assembled.  (Keeping the first Newton system's
         // hierarchy for the later iterations of a solve was measured: 96.6 ms per step either way at 10M DOF -- not kept.)
@@ -653,9 +672,20 @@ static int krylov_solve(Ctx* c, int* its, int* converged, double* relres, bool f
     // (shk_newton_solve); the solve's target is max(rtol ||F||, atol, newton_floor)
     const double rtol = c->params.krylov_rtol, atol = std::max(c->params.krylov_atol, newton_floor);
     int total = 0, conv = 0;
-    double target = 0.0, rhs_norm = 0.0, rt = 0.0, rt_prev = 0.0;
+    double target = 0.0, rhs_norm = 0.0, rt = 0.0, rt_prev = 0.0, r_start = 0.0;
     const int max_outer = 12;
-    for (int outer = 0; outer < max_outer; ++outer) {
+    // warm start (first solve of a time step inside shk_newton_solve, which knows ||F||): the loop then begins with
+    // the correction equation of the projected guess, as if a first pass had already run
+    const int depth = c->params.krylov_warm_start;
+    const bool warmable = depth > 0 && fnorm > 0.0 && newton_it >= 0 && newton_it < c->warm_its;
+    const bool warm = warmable && std::min(c->n_guess[newton_it], depth) > 0;
+    if (warm) {
+        HIPCHK(launch_warm_start(c, newton_it));
+        rhs_norm = fnorm;
+        target = std::max(rtol * rhs_norm, atol);
+        rt_prev = HUGE_VAL;
+    }
+    for (int outer = warm ? 1 : 0; outer < max_outer; ++outer) {
         if (outer == 0) { c->cur_rtol2 = rtol * rtol; c->cur_atol2 = atol * atol; }
         else { c->cur_rtol2 = 0.0; c->cur_atol2 = target * target; }
         KrylovState st{};
@@ -663,6 +693,7 @@ static int krylov_solve(Ctx* c, int* its, int* converged, double* relres, bool f
         if (budget <= 0) break;
         if (krylov_inner(c, outer == 0 ? c->d_F : c->d_rhs, budget, &st)) return -1;
         total += st.its;
+        if (warm && outer == 1) r_start = std::sqrt(st.rhs2);
         if (outer == 0) {
             rhs_norm = std::sqrt(st.rhs2);
             target = std::max(rtol * rhs_norm, atol);
@@ -678,9 +709,20 @@ static int krylov_solve(Ctx* c, int* its, int* converged, double* relres, bool f
         rt_prev = rt;
     }
     HIPCHK(hipGetLastError());
+    if (warmable && conv) {   // keep this solution for the same Newton iteration of the next steps: newest first
+        if (warm_alloc(c, newton_it)) return -1;
+        double** g = c->d_guess[newton_it];
+        std::rotate(g, g + Ctx::kWarmDepth - 1, g + Ctx::kWarmDepth);
+        HIPCHK(hipMemcpyAsync(c->d_guess[newton_it][0], c->d_ytot, (size_t)c->n_own * sizeof(double), hipMemcpyDeviceToDevice,
+                              c->stream));
+        c->n_guess[newton_it] = std::min(c->n_guess[newton_it] + 1, (int)Ctx::kWarmDepth);
+    }
     if (c->use_amg && first_of_step) {  // feedback for the coarsest-inverse refresh policy (like with like:
-        c->amg->its_last = total;       // only the first Newton system of each solve is compared)
-        if (c->amg->its_fresh == 0) c->amg->its_fresh = total;
+        int cost = total;               // only the first Newton system of each solve is compared)
+        if (warm && r_start > target && rhs_norm > target)   // a warm start covers fewer decades: scale to the full span
+            cost = (int)std::lround(total * std::log(rhs_norm / target) / std::log(r_start / target));
+        c->amg->its_last = cost;
+        if (c->amg->its_fresh == 0) c->amg->its_fresh = cost;
     }
     if (its) *its = total;
     if (converged) *converged = conv;
@@ -750,7 +792,7 @@ int shk_newton_solve(shk_ctx* ctx, double dt, shk_solve_info* info) {
         // iteration is unaffected: 0.1 x 1e-9 ||F_0|| = krylov_rtol ||F_0||).  Newton counts stay those of the LU oracle
         // in every parity test; 0 restores the pure relative rule.
         const double newton_target = std::max(c->params.newton_atol, c->params.newton_rtol * I.residual0);
-        if (krylov_solve(c, &k, &kc, &rr, it == 0, c->params.krylov_newton_eta * newton_target)) return -1;
+        if (krylov_solve(c, &k, &kc, &rr, it, c->params.krylov_newton_eta * newton_target, r)) return -1;
         I.krylov_its += k;
         // a solve that stagnated between krylov_rtol and krylov_fail_rtol sits on its fp64 floor
         // eps || |J| |dx| || (Newton absorbs it); beyond that -- max_it, breakdown, divergence -- it has failed

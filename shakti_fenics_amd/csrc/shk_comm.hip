@@ -315,4 +315,11 @@ hipError_t allreduce_parts(Ctx* c, int first, int nslots) {
     return allreduce_buffer(c, c->d_red + first, c->d_red + first, (size_t)nslots);
 }
 
+// The same for partial arrays outside the Krylov slots (`part`: nslots arrays of kMaxParts, c->grid entries used):
+// fixed-order local sums into red[0 .. nslots), then one all-reduce.
+hipError_t allreduce_part_arrays(Ctx* c, const double* part, double* red, int nslots) {
+    hipLaunchKernelGGL(k_reduce_parts, dim3(nslots), dim3(kBlock), 0, c->stream, c->grid, part, 0, (const double*)nullptr, red);
+    return allreduce_buffer(c, red, red, (size_t)nslots);
+}
+
 }  // namespace shk

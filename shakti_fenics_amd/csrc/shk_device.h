@@ -464,6 +464,13 @@ struct Ctx {
     double *d_r = nullptr, *d_rhat = nullptr, *d_p = nullptr, *d_v = nullptr, *d_s = nullptr, *d_t = nullptr,
            *d_y = nullptr, *d_ytot = nullptr, *d_rhs = nullptr;
     double cur_rtol2 = 0.0, cur_atol2 = 0.0;   // stopping rule of the inner solve being enqueued
+    // launch_warm_start: solutions of Newton iteration k (< kWarmIts) of the last kWarmDepth time steps, newest
+    // first (allocated on first use: shk_api.hip warm_alloc)
+    static constexpr int kWarmIts = 3, kWarmDepth = 4, kWarmDots = kWarmDepth + kWarmDepth * (kWarmDepth + 1) / 2;
+    double* d_guess[kWarmIts][kWarmDepth] = {};
+    int n_guess[kWarmIts] = {};
+    double *d_part_w = nullptr, *d_red_w = nullptr;   // kWarmDots partial arrays / all-reduced scalars
+    int warm_its = kWarmIts;
     // multigrid preconditioner (empty when unavailable: subdomain contexts, tiny meshes)
     AmgHierarchy amg_local, amg_dist;
     AmgHierarchy* amg = nullptr;    // the active one when use_amg
@@ -528,6 +535,7 @@ void launch_stream_read(Ctx* c);
 void krylov_init(Ctx* c, const double* rhs);
 void launch_accumulate(Ctx* c, bool first);
 hipError_t launch_true_residual(Ctx* c);
+hipError_t launch_warm_start(Ctx* c, int newton_it);
 hipError_t krylov_iteration(Ctx* c, int it);
 void launch_newton_update(Ctx* c, bool apply);
 hipError_t launch_update_explicit(Ctx* c, double dt);
@@ -560,6 +568,7 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
                       const std::vector<int32_t>* krank0 = nullptr);   // krank0: k-d ranks of the top rows (default: the mesh's)
 hipError_t amg_upload_rep_top(Ctx* c, AmgHierarchy& R, const SellPattern& G, const std::vector<int32_t>& diag_slot);
 hipError_t allreduce_parts(Ctx* c, int first, int nslots);
+hipError_t allreduce_part_arrays(Ctx* c, const double* part, double* red, int nslots);   // any partial arrays -> scalars
 
 struct PhaseTimer {  // RAII hipEvent pair when profiling is on
     Ctx* c;

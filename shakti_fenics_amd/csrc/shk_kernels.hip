@@ -312,6 +312,139 @@ void launch_accumulate(Ctx* c, bool first) {
     hipLaunchKernelGGL(k_accumulate, dim3(c->grid), dim3(kBlock), 0, c->stream, c->n_own, first ? 1 : 0, c->d_y,
                        c->d_ytot);
 }
+// Warm start of the linear solve of Newton iteration k of a time step from the solutions g_1 .. g_m of iteration k
+// of the previous m <= kWarmDepth steps (Ctx::d_guess, newest first): the combination sum_j c_j g_j that minimises
+// ||F - A' sum_j c_j g_j|| becomes the initial iterate, so the guesses can only lower the starting residual.  The normal
+// equations (Gram matrix of the images t_j = A' g_j, m + m (m + 1) / 2 dot products in one pass) are solved in every
+// workgroup by a Cholesky factorisation that drops a guess whose image is numerically inside the span of the newer
+// ones.  Consecutive steps of a slow transient ask for nearly the same Newton updates, and m of them extrapolate.
+struct WarmArgs {
+    int64_t n;
+    int m, np, rs;
+    const double* g[Ctx::kWarmDepth];
+    const double* t[Ctx::kWarmDepth];
+    const double* F;
+    double* part;          // kWarmDots partial arrays
+    const double* red;     // what k_warm_apply sums: the partial arrays, or the all-reduced scalars
+    double *ytot, *rhs;
+};
+__global__ __launch_bounds__(kBlock) void k_warm_dots(const WarmArgs a) {
+    __shared__ double sh4[4];
+    constexpr int M = Ctx::kWarmDepth;
+    double b[M], G[M * (M + 1) / 2];
+#pragma unroll
+    for (int j = 0; j < M; ++j) b[j] = 0.0;
+#pragma unroll
+    for (int j = 0; j < M * (M + 1) / 2; ++j) G[j] = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * kBlock) {
+        const double f = a.F[i];
+        double t[M];
+#pragma unroll
+        for (int j = 0; j < M; ++j) t[j] = j < a.m ? a.t[j][i] : 0.0;
+#pragma unroll
+        for (int j = 0, q = 0; j < M; ++j) {
+            b[j] += t[j] * f;
+#pragma unroll
+            for (int l = 0; l <= j; ++l, ++q) G[q] += t[j] * t[l];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        const double v = block_sum(b[j], sh4);
+        if (threadIdx.x == 0) a.part[j * kMaxParts + blockIdx.x] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < M * (M + 1) / 2; ++q) {
+        const double v = block_sum(G[q], sh4);
+        if (threadIdx.x == 0) a.part[(M + q) * kMaxParts + blockIdx.x] = v;
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_warm_apply(const WarmArgs a) {
+    __shared__ double sh4[4];
+    constexpr int M = Ctx::kWarmDepth;
+    double b[M], G[M][M], c[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) b[j] = reduce_partials(a.red + j * a.rs, a.np, sh4);
+#pragma unroll
+    for (int j = 0, q = 0; j < M; ++j)
+#pragma unroll
+        for (int l = 0; l <= j; ++l, ++q) G[j][l] = reduce_partials(a.red + (M + q) * a.rs, a.np, sh4);
+    // Cholesky G = L L^T in place (lower triangle), forward / backward substitution; a pivot below 1e-8 of its
+    // diagonal entry (the image is, to 4 digits, a combination of the newer ones) removes that guess
+    bool keep[M];
+    bool finite = true;
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        double d = G[j][j];
+        const double d0 = d;
+#pragma unroll
+        for (int l = 0; l < j; ++l) if (keep[l]) d -= G[j][l] * G[j][l];
+        keep[j] = j < a.m && d0 > 0.0 && d > 1e-8 * d0;
+        finite = finite && isfinite(d0);
+        if (!keep[j]) continue;
+        G[j][j] = sqrt(d);
+#pragma unroll
+        for (int i = j + 1; i < M; ++i) {
+            double v = G[i][j];
+#pragma unroll
+            for (int l = 0; l < j; ++l) if (keep[l]) v -= G[i][l] * G[j][l];
+            G[i][j] = v / G[j][j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < M; ++j) {   // L z = b
+        double v = b[j];
+#pragma unroll
+        for (int l = 0; l < j; ++l) if (keep[l]) v -= G[j][l] * c[l];
+        c[j] = keep[j] ? v / G[j][j] : 0.0;
+    }
+#pragma unroll
+    for (int j = M - 1; j >= 0; --j) {   // L^T c = z
+        double v = c[j];
+#pragma unroll
+        for (int l = j + 1; l < M; ++l) if (keep[l]) v -= G[l][j] * c[l];
+        c[j] = keep[j] ? v / G[j][j] : 0.0;
+        finite = finite && isfinite(c[j]);
+    }
+    // guesses holding NaN / Inf: start from zero
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * kBlock) {
+        double y = 0.0, r = a.F[i];
+        if (finite) {
+#pragma unroll
+            for (int j = 0; j < M; ++j)
+                if (c[j] != 0.0) { y += c[j] * a.g[j][i]; r -= c[j] * a.t[j][i]; }
+        }
+        a.ytot[i] = y;
+        a.rhs[i] = r;
+    }
+}
+hipError_t launch_warm_start(Ctx* c, int k) {   // d_ytot = the projected guess, d_rhs = F - A' d_ytot
+    const double* A = c->use_amg ? c->d_vals : c->d_vals_s;
+    double* images[Ctx::kWarmDepth] = {c->d_t, c->d_v, c->d_s, c->d_p};   // Krylov vectors, free between solves
+    WarmArgs a{};
+    a.n = c->n_own; a.m = std::min(c->n_guess[k], (int)c->params.krylov_warm_start); a.F = c->d_F; a.part = c->d_part_w; a.ytot = c->d_ytot; a.rhs = c->d_rhs;
+    hipError_t e;
+    for (int j = 0; j < a.m; ++j) {
+        if ((e = halo_exchange(c, c->d_guess[k][j])) != hipSuccess) return e;
+        launch_spmv_plain(c, A, c->d_guess[k][j], images[j]);
+        a.g[j] = c->d_guess[k][j];
+        a.t[j] = images[j];
+    }
+    {
+        PhaseTimer t(c, SHK_PH_VECTOR);
+        hipLaunchKernelGGL(k_warm_dots, dim3(c->grid), dim3(kBlock), 0, c->stream, a);
+    }
+    // one subdomain: the consumers sum the partial arrays themselves; several: fixed-order local sums, one all-reduce
+    a.red = c->d_part_w; a.np = c->grid; a.rs = kMaxParts;
+    if (c->comm.kind != Comm::NONE && c->comm.nranks > 1) {
+        if ((e = allreduce_part_arrays(c, c->d_part_w, c->d_red_w, Ctx::kWarmDots)) != hipSuccess) return e;
+        a.red = c->d_red_w; a.np = 1; a.rs = 1;
+    }
+    PhaseTimer t(c, SHK_PH_VECTOR);
+    hipLaunchKernelGGL(k_warm_apply, dim3(c->grid), dim3(kBlock), 0, c->stream, a);
+    return hipSuccess;
+}
+
 // Boundary pass of a split product: the flagged slices, after the ghosts have arrived.  Accounted to the halo
 // phase (it is the part of the product that had to wait for the exchange).
 template <int MODE, class TX>

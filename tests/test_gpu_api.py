@@ -68,13 +68,18 @@ def test_pde_solver_object_api(tmp_path):
     solver.ctx.close()
 
 
-def test_restart_continues_bit_for_bit(tmp_path):
-    """resume from the saved frames (the reference has no restart path)."""
+@pytest.mark.parametrize("warm", [0, 4])
+def test_restart_continues_bit_for_bit(tmp_path, warm):
+    """resume from the saved frames (the reference has no restart path).  With every linear solve
+    started from zero (md.krylov_warm_start = 0) the continuation is bit-identical to the uninterrupted run; with the
+    default warm start a resumed run has no previous solutions to start from, takes different Krylov paths to the same
+    tolerance and agrees to 1e-8 with identical Newton counts."""
     from shakti_fenics_amd.setups import setup_synthetic_cooke2 as S
 
     def fresh(root):
         md = S.initialize(SerialComm(), nx=31, ny=31, days=8.0 / 24.0, results_root=root)
         md.nt_check = 1
+        md.krylov_warm_start = warm
         return md
 
     md = fresh(tmp_path / "full")
@@ -89,7 +94,12 @@ def test_restart_continues_bit_for_bit(tmp_path):
     md3.restart = True
     md3.solve()
     for k, ref in full.items():
-        assert np.array_equal(np.load(f"{md3.results_name}/{k}.npy"), ref), k
+        got = np.load(f"{md3.results_name}/{k}.npy")
+        if warm == 0 or k == "newton_its":
+            assert np.array_equal(got, ref), k
+        else:
+            assert np.array_equal(got[:4], ref[:4]), k
+            assert rel_l2(got[-1], ref[-1]) < 1e-8, k
 
 
 def test_restart_on_a_mesh_with_a_large_dense_level_agrees_to_solver_tolerance(tmp_path):

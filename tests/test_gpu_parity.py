@@ -147,6 +147,41 @@ def test_hundred_steps_do_not_drift_from_the_lu_oracle(hip):
     ctx.close()
 
 
+def test_warm_started_linear_solves_change_iteration_counts_not_results(hip):
+    """shk_params.krylov_warm_start: the solve of Newton iteration k starts from the least-squares combination of the
+    solutions of iteration k of the previous (up to 4) steps.  Over 30 steps with storage and moulins, with the warm
+    start (the default) and without: both trajectories follow the LU oracle's to 1e-7 with ITS Newton counts at every
+    step, and the warm-started run needs clearly fewer Krylov iterations."""
+    dom, f, bc, g = make_case(nx=61, ny=61, Lx=100e3, Ly=100e3, moulins=2)
+    ts = np.arange(31) * DT
+    fo, log = O.run(dom.xy, dom.cells, f.copy(), ts, O.Params(), bc, g, nsteps=30)
+    krylov = {}
+    for warm in (4, 2, 0):
+        ctx = hip.ShaktiHip(dom.xy, dom.cells)
+        ctx.set_params(precond=hip.PRECOND["amg"], krylov_warm_start=warm)
+        assert ctx.get_params().krylov_warm_start == warm
+        upload(ctx, f, bc, g)
+        its, k = [], 0
+        for i in range(30):
+            info = ctx.step(0.1 * DT if i == 0 else DT)
+            assert info.converged and not info.krylov_failed
+            its.append(info.newton_its)
+            k += info.krylov_its
+        assert its == [l["niter"] for l in log], warm
+        assert rel_l2(ctx.get_field("N"), fo.N) < 1e-7
+        assert rel_l2(ctx.get_field("b"), fo.b) < 1e-7
+        assert rel_l2(ctx.get_field("q"), fo.q) < 1e-6
+        krylov[warm] = k
+        ctx.close()
+    assert krylov[4] < 0.85 * krylov[0] and krylov[2] < 0.9 * krylov[0], krylov
+    with pytest.raises(hip.ShaktiHipError):
+        ctx = hip.ShaktiHip(dom.xy, dom.cells)
+        try:
+            ctx.set_params(krylov_warm_start=5)
+        finally:
+            ctx.close()
+
+
 def test_three_steps_at_62k_dof_match_oracle(hip):
     """The largest size the LU oracle finishes in seconds (the mesh of bench.py's cpu_baseline leg, 560 x 112 on the
     100 km x 20 km geometry, with the lake storage term and 12 moulins): a multigrid hierarchy of four levels, the
