@@ -812,6 +812,7 @@ hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense, bool d
         if (refresh_dense && D.dense_valid && nd > 512) {
             const bool degraded = H.its_fresh > 0 && H.its_last > 1.25 * H.its_fresh;
             if (++D.dense_age < D.dense_period && !degraded) refresh_dense = false;
+            if (degraded) H.lambda_age = INT_MAX / 2;   // ... and the spectral estimates with it
         }
         if (!D.dense_valid) refresh_dense = true;
         if (refresh_dense) { D.dense_age = 0; H.its_fresh = 0; }
@@ -869,7 +870,17 @@ hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense, bool d
             fine = L.vals;
         }
     }
-    if (refresh_dense || H.lambda == 0.0) return estimate_lambda(c, H);
+    // Spectral estimates (power steps, Lanczos, Gershgorin on every sparse level: ~22 ms at 10M rows, most of it the
+    // host round trips of the Lanczos recurrences) belong to the slowest-moving part of the setup: lambda_max(D^-1 A)
+    // depends on the mesh and on the anisotropy of the coefficients, not on their size.  They are renewed with every
+    // lambda_period-th refresh of the dense inverse (4: every 32nd step), at once when the iteration feedback reports
+    // a degraded preconditioner, and with every refresh on hierarchies too small to be worth the bookkeeping.
+    static const int lambda_period = getenv("SHK_AMG_LAMBDA_PERIOD") ? std::max(1, atoi(getenv("SHK_AMG_LAMBDA_PERIOD"))) : 4;
+    const bool small = H.topA.n_rows < 200000;
+    if (H.lambda == 0.0 || (refresh_dense && (small || ++H.lambda_age >= lambda_period))) {
+        H.lambda_age = 0;
+        return estimate_lambda(c, H);
+    }
     return hipSuccess;
 }
 

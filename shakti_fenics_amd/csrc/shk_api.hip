@@ -593,8 +593,9 @@ static hipError_t wait_stream(Ctx* c) {
 static int krylov_inner(Ctx* c, const double* rhs, int max_it, KrylovState* out) {
     krylov_init(c, rhs);
     // iterations enqueued per stop-flag poll: 0 = auto (a multigrid iteration is ~90 launches: poll often)
+    static const int env_chunk = getenv("SHK_KRYLOV_CHUNK") ? atoi(getenv("SHK_KRYLOV_CHUNK")) : 0;   // experiments
     const int chunk = c->params.krylov_check_every > 0 ? c->params.krylov_check_every
-                      : c->use_amg ? 2 : 16;
+                      : env_chunk > 0 ? env_chunk : c->use_amg ? 2 : 16;
     int it = 0, slot = 0;
     const int saved_max = c->params.krylov_max_it;
     c->params.krylov_max_it = max_it;

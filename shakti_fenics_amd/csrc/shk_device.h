@@ -356,6 +356,7 @@ struct AmgHierarchy {
     // below).  c = (2.35, 1.41) is the pair measured best on the 10M-row system (lambda there = 2.35: w = 1.0,
     // 0.6; 61 iterations per Newton step against 69 for 0.7, 0.7 -- and 0.9, 0.9 diverges).  (SHK_AMG_W1/W2)
     double lambda = 0.0;             // 0: not estimated yet
+    int lambda_age = 0;              // dense-inverse refreshes since the spectral estimates were renewed
     double gersh = 0.0;              // Gershgorin bound of lambda_max(D^-1 A) over the levels (rigorous, unlike lambda)
     double lam_max = 0.0;            // spectral bound the caps use: min(gersh, 1.05 x Lanczos estimate)
     double cap2 = 1.0, cap4 = 1.0;   // factors <= 1 on the two- / four-sweep dampings: no amplification on (0, gersh]
