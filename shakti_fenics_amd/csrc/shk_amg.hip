@@ -796,9 +796,19 @@ static void bind_top_to_jacobian(Ctx* c, AmgHierarchy& H) {
     H.top_dinv = c->d_dinv32;
 }
 
-hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense, bool decided) {
+hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense, bool decided, bool top_only) {
     const bool primary = &H == &c->amg_local || &H == &c->amg_dist;
     if (primary) bind_top_to_jacobian(c, H);
+    // top_only: a later Newton iteration whose iterate has barely moved (shk_newton_solve decides) keeps the coarse
+    // operators and A*P of the step's first system and renews only the finest level's float copy: the cycle stays a
+    // fixed linear operator, marginally staler (10M rows: +4..9 Krylov iterations in 550, -1.4 ms per step).
+    static const bool reuse = !(getenv("SHK_AMG_REUSE") && atoi(getenv("SHK_AMG_REUSE")) == 0);
+    if (top_only && reuse && primary && !refresh_dense && !decided && H.lambda != 0.0) {
+        PhaseTimer t(c, SHK_PH_OTHER);
+        hipLaunchKernelGGL(k_narrow, dim3(c->grid), dim3(kBlock), 0, c->stream, c->slots, c->d_vals, c->d_vals32);
+        hipLaunchKernelGGL(k_narrow, dim3(small_grid(c->n_own)), dim3(kBlock), 0, c->stream, c->n_own, c->d_dinv, c->d_dinv32);
+        return hipSuccess;
+    }
     // a large dense coarsest inverse (2 launches per pivot) is only rebuilt when asked to: between the Newton
     // iterations of one time step the coarsest operator barely moves, and a slightly stale inverse only makes
     // the (fixed, linear) preconditioner marginally weaker

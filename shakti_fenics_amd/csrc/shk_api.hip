@@ -659,12 +659,12 @@ static int warm_alloc(Ctx* c, int newton_it) {
 }
 
 static int krylov_solve(Ctx* c, int* its, int* converged, double* relres, int newton_it = 0,
-                        double newton_floor = 0.0, double fnorm = -1.0) {
+                        double newton_floor = 0.0, double fnorm = -1.0, bool iterate_moved_little = false) {
     const bool first_of_step = newton_it == 0;
     if (c->use_amg) {
         // Galerkin coarse operators (and the float copy) of the Jacobian just assembled.  (Keeping the first Newton system's
         // hierarchy for the later iterations of a solve was measured: 96.6 ms per step either way at 10M DOF -- not kept.)
-        HIPCHK(amg_numeric_setup(c, *c->amg, first_of_step));
+        HIPCHK(amg_numeric_setup(c, *c->amg, first_of_step, false, !first_of_step && iterate_moved_little));
     } else {
         HIPCHK(halo_exchange(c, c->d_dinv));  // ghost columns of A' = A D^-1 need their owners' diagonal
         launch_scale(c);
@@ -793,7 +793,9 @@ int shk_newton_solve(shk_ctx* ctx, double dt, shk_solve_info* info) {
         // iteration is unaffected: 0.1 x 1e-9 ||F_0|| = krylov_rtol ||F_0||).  Newton counts stay those of the LU oracle
         // in every parity test; 0 restores the pure relative rule.
         const double newton_target = std::max(c->params.newton_atol, c->params.newton_rtol * I.residual0);
-        if (krylov_solve(c, &k, &kc, &rr, it, c->params.krylov_newton_eta * newton_target, r)) return -1;
+        // (an iterate whose residual is already 1e-3 of the step's first one has barely moved: the multigrid keeps its coarse
+        // operators, amg_numeric_setup's top_only)
+        if (krylov_solve(c, &k, &kc, &rr, it, c->params.krylov_newton_eta * newton_target, r, it > 0 && r < 1e-3 * I.residual0)) return -1;
         I.krylov_its += k;
         // a solve that stagnated between krylov_rtol and krylov_fail_rtol sits on its fp64 floor
         // eps || |J| |dx| || (Newton absorbs it); beyond that -- max_it, breakdown, divergence -- it has failed

@@ -562,7 +562,7 @@ hipError_t halo_begin_f32(Ctx* c, float* vec);
 hipError_t halo_end(Ctx* c);
 hipError_t allreduce_buffer(Ctx* c, const double* src, double* dst, size_t n);  // element-wise sum over subdomains
 int amg_setup_distributed(Ctx* c, std::string& err);  // collective
-hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense, bool decided = false);
+hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense, bool decided = false, bool top_only = false);
 hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout);
 // upload one host hierarchy (shk_api.hip: owns the allocation helpers)
 hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H, int64_t n_loc0,
