@@ -10,6 +10,10 @@ solve for N (fused P1 assembly + one BiCGStab solve per Newton iteration, right-
 aggregation multigrid of DESIGN.md 4b; `--precond jacobi` selects north_star's Jacobi, which diverges at
 10M DOF) followed by the fused flux / melt / gap-height updates.
 value = Nv * (Newton iterations in the timed steps) / wall time.  Rank 0 prints ONE JSON line.
+Every step assembles, refreshes the preconditioner and solves every Newton system to the same true-residual rule; the
+linear solves start from a least-squares combination of the previous steps' solutions (shk_params.krylov_warm_start,
+DESIGN.md section 4) and stop at Newton's own threshold (krylov_newton_eta).  `strict_linear_solves` in the line is
+the same workload with both switched off (round 1's rule), `--warm-start 0` switches the first off for the whole run.
 
 After the timed region (never inside it): one profiled step for the roofline legs; the steady-state march
 of configurations C2 / C4 (until ||dN|| / ||N|| < 1e-8 or 50 steps, reporting which); the CPU
