@@ -182,6 +182,39 @@ def test_warm_started_linear_solves_change_iteration_counts_not_results(hip):
             ctx.close()
 
 
+def test_warm_start_survives_abrupt_changes_of_the_forcing(hip):
+    """The kept solutions are only a starting point: when the moulin input jumps by a factor 20 after step 6 and is
+    switched off after step 11 (the previous steps' Newton updates then say little about the next one), the projected
+    start is poor, the solves take longer, and the results still follow the LU oracle's with its Newton counts."""
+    dom, f, bc, g = make_case(nx=61, ny=61, Lx=100e3, Ly=100e3, moulins=3)
+    base = f.inputs.copy()
+    schedule = {6: 20.0, 11: 0.0}
+
+    def forcing(i, fo):   # after step i: the forcing of the following steps
+        if i in schedule:
+            fo.inputs = schedule[i] * base
+
+    ts = np.arange(17) * DT
+    fo, log = O.run(dom.xy, dom.cells, f.copy(), ts, O.Params(), bc, g, nsteps=16, callback=forcing)
+    ctx = hip.ShaktiHip(dom.xy, dom.cells)
+    ctx.set_params(precond=hip.PRECOND["amg"])
+    assert ctx.get_params().krylov_warm_start == 4
+    upload(ctx, f, bc, g)
+    its, krylov = [], []
+    for i in range(16):
+        info = ctx.step(0.1 * DT if i == 0 else DT)
+        assert info.converged and not info.krylov_failed
+        its.append(info.newton_its)
+        krylov.append(info.krylov_its)
+        if i in schedule:
+            ctx.set_field("inputs", schedule[i] * base)
+    assert its == [l["niter"] for l in log], (its, [l["niter"] for l in log])
+    assert rel_l2(ctx.get_field("N"), fo.N) < 1e-7
+    assert rel_l2(ctx.get_field("b"), fo.b) < 1e-7
+    assert rel_l2(ctx.get_field("q"), fo.q) < 1e-6
+    ctx.close()
+
+
 def test_three_steps_at_62k_dof_match_oracle(hip):
     """The largest size the LU oracle finishes in seconds (the mesh of bench.py's cpu_baseline leg, 560 x 112 on the
     100 km x 20 km geometry, with the lake storage term and 12 moulins): a multigrid hierarchy of four levels, the
