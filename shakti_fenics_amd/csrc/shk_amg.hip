@@ -28,16 +28,66 @@
 namespace shk {
 
 
-// coarse[s] = sum of the finer values listed for slot s (ascending fine slot: fixed order), accumulated in double
-template <class TC>
+// coarse[s] = sum of the finer values listed for slot s (ascending fine slot: fixed order), accumulated in double.
+// ILP slots per thread at a time, kBlock apart (their list bounds first, then the gather chains side by side): the
+// kernel is a chain of three dependent loads per entry.  Which ILP / grid is fastest differs between the operators
+// (measured at 10M rows, profiles/r02_galerkin_variants.md): see launch_galerkin.
+template <class TC, int ILP>
 __global__ __launch_bounds__(kBlock) void k_galerkin(int64_t nslots, const int32_t* __restrict__ gptr,
                                                      const int32_t* __restrict__ glist,
                                                      const float* __restrict__ fine, TC* __restrict__ coarse) {
-    for (int64_t s = blockIdx.x * (int64_t)kBlock + threadIdx.x; s < nslots; s += (int64_t)gridDim.x * kBlock) {
-        double a = 0.0;
-        for (int32_t k = gptr[s]; k < gptr[s + 1]; ++k) a += (double)fine[glist[k]];
-        coarse[s] = (TC)a;
+    constexpr int64_t kChunk = (int64_t)ILP * kBlock;
+    for (int64_t c0 = blockIdx.x * kChunk; c0 < nslots; c0 += (int64_t)gridDim.x * kChunk) {
+        int32_t b[ILP], e[ILP];
+        double a[ILP];
+        int len = 0;
+#pragma unroll
+        for (int j = 0; j < ILP; ++j) {
+            const int64_t s = c0 + threadIdx.x + (int64_t)j * kBlock;
+            b[j] = s < nslots ? gptr[s] : 0;
+            e[j] = s < nslots ? gptr[s + 1] : 0;
+            a[j] = 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < ILP; ++j) len = max(len, e[j] - b[j]);
+        if (ILP == 1) {
+            // one slot per thread: four list entries at a time (indices first, then the four gathers; added in list order)
+            for (int k = b[0]; k < e[0]; k += 4) {
+                int32_t idx[4];
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) idx[u] = k + u < e[0] ? glist[k + u] : -1;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = idx[u] >= 0 ? fine[idx[u]] : 0.0f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (idx[u] >= 0) a[0] += (double)v[u];
+            }
+        } else {
+            for (int k = 0; k < len; ++k) {
+                int32_t idx[ILP];
+#pragma unroll
+                for (int j = 0; j < ILP; ++j) idx[j] = b[j] + k < e[j] ? glist[b[j] + k] : -1;
+#pragma unroll
+                for (int j = 0; j < ILP; ++j) if (idx[j] >= 0) a[j] += (double)fine[idx[j]];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < ILP; ++j) {
+            const int64_t s = c0 + threadIdx.x + (int64_t)j * kBlock;
+            if (s < nslots) coarse[s] = (TC)a[j];
+        }
     }
+}
+// kind 0: a coarse operator P^T A P (long, uneven lists), kind 1: A*P (1-2 entries per slot)
+template <class TC>
+static void launch_galerkin(Ctx* c, int kind, int64_t nslots, const int32_t* gptr, const int32_t* glist, const float* fine, TC* coarse) {
+    static const int ilp_env[2] = {getenv("SHK_GAL_ILP0") ? atoi(getenv("SHK_GAL_ILP0")) : 1, getenv("SHK_GAL_ILP1") ? atoi(getenv("SHK_GAL_ILP1")) : 4};
+    static const int grid_env[2] = {getenv("SHK_GAL_GRID0") ? atoi(getenv("SHK_GAL_GRID0")) : 1024, getenv("SHK_GAL_GRID1") ? atoi(getenv("SHK_GAL_GRID1")) : 2048};
+    const int ilp = ilp_env[kind];
+    const int g = (int)std::min<int64_t>(grid_env[kind], std::max<int64_t>(1, (nslots + (int64_t)ilp * kBlock - 1) / ((int64_t)ilp * kBlock)));
+    if (ilp == 4) hipLaunchKernelGGL((k_galerkin<TC, 4>), dim3(g), dim3(kBlock), 0, c->stream, nslots, gptr, glist, fine, coarse);
+    else if (ilp == 2) hipLaunchKernelGGL((k_galerkin<TC, 2>), dim3(g), dim3(kBlock), 0, c->stream, nslots, gptr, glist, fine, coarse);
+    else hipLaunchKernelGGL((k_galerkin<TC, 1>), dim3(g), dim3(kBlock), 0, c->stream, nslots, gptr, glist, fine, coarse);
 }
 
 __global__ __launch_bounds__(kBlock) void k_diag_inv(int32_t n, const int32_t* __restrict__ diag_slot,
@@ -836,14 +886,12 @@ hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense, bool d
     for (size_t l = 0; l < H.xf.size(); ++l) {
         const AmgXfer& X = H.xf[l];
         if (X.with_ap)
-            hipLaunchKernelGGL(k_galerkin<float>, dim3(small_grid(X.ap_slots)), dim3(kBlock), 0, c->stream, X.ap_slots,
-                               X.ap_gptr, X.ap_glist, fine, X.ap_vals);
+            launch_galerkin<float>(c, 1, X.ap_slots, X.ap_gptr, X.ap_glist, fine, X.ap_vals);
         if (X.onto_global) {
             // my rows of the replicated global level (zeros elsewhere), completed by one all-reduce; then the
             // replicated hierarchy refreshes itself from it, identically on every subdomain
             AmgHierarchy& R = *H.rep;
-            hipLaunchKernelGGL(k_galerkin<double>, dim3(small_grid(R.t_slots)), dim3(kBlock), 0, c->stream, R.t_slots,
-                               X.gptr, X.glist, fine, H.rep_gtmp);
+            launch_galerkin<double>(c, 0, R.t_slots, X.gptr, X.glist, fine, H.rep_gtmp);
             hipError_t e = allreduce_buffer(c, H.rep_gtmp, H.rep_gtmp, (size_t)R.t_slots);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(k_narrow, dim3(small_grid(R.t_slots)), dim3(kBlock), 0, c->stream, R.t_slots,
@@ -857,13 +905,13 @@ hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense, bool d
                 const size_t all = (size_t)H.n_glob * H.n_glob;
                 hipError_t e = hipMemsetAsync(H.cdense, 0, all * sizeof(double), c->stream);
                 if (e != hipSuccess) return e;
-                hipLaunchKernelGGL(k_galerkin<double>, dim3(small_grid(ns)), dim3(kBlock), 0, c->stream, ns, X.gptr,
+                launch_galerkin<double>(c, 0, ns, X.gptr,
                                    X.glist, fine, H.cdense + (size_t)H.offset * H.n_glob);
                 if ((e = allreduce_buffer(c, H.cdense, H.cdense, all)) != hipSuccess) return e;
                 if (refresh_dense || H.n_glob <= 64) dense_invert_big(c, H.n_glob, H.cdense, H.cinv, H.gj);
                 H.dense_valid = true;
             } else {
-                hipLaunchKernelGGL(k_galerkin<double>, dim3(small_grid(ns)), dim3(kBlock), 0, c->stream, ns, X.gptr,
+                launch_galerkin<double>(c, 0, ns, X.gptr,
                                    X.glist, fine, H.cdense);
                 if (X.n_coarse <= 64)
                     hipLaunchKernelGGL(k_dense_invert, dim3(1), dim3(kBlock), 0, c->stream, X.n_coarse, H.cdense, H.cinv);
@@ -873,8 +921,7 @@ hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense, bool d
             }
         } else {
             AmgLevel& L = H.lv[l + 1];
-            hipLaunchKernelGGL(k_galerkin<float>, dim3(small_grid(L.slots)), dim3(kBlock), 0, c->stream, L.slots,
-                               X.gptr, X.glist, fine, L.vals);
+            launch_galerkin<float>(c, 0, L.slots, X.gptr, X.glist, fine, L.vals);
             hipLaunchKernelGGL(k_diag_inv, dim3(small_grid(L.n)), dim3(kBlock), 0, c->stream, L.n, L.diag_slot, L.vals,
                                L.dinv);
             fine = L.vals;
