@@ -218,11 +218,11 @@ static void launch_spmm(Ctx* c, const double* vals, int m, double* const* x, dou
     if (m == 1) { launch_spmv_plain(c, vals, x[0], y[0]); return; }
     if (m == 2) {
         SpmmArgs<2> a{c->sell(), vals, {x[0], x[1]}, {y[0], y[1]}};
-        launch_phase(c, SHK_PH_SPMV, k_spmm<2>, dim3(c->grid), dim3(kBlock), 0, a);
+        launch_phase(c, SHK_PH_VECTOR, k_spmm<2>, dim3(c->grid), dim3(kBlock), 0, a);   // (not the Krylov product's leg)
         return;
     }
     SpmmArgs<4> a{c->sell(), vals, {x[0], x[1], x[2], x[m > 3 ? 3 : 2]}, {y[0], y[1], y[2], y[m > 3 ? 3 : 2]}};
-    launch_phase(c, SHK_PH_SPMV, k_spmm<4>, dim3(c->grid), dim3(kBlock), 0, a);
+    launch_phase(c, SHK_PH_VECTOR, k_spmm<4>, dim3(c->grid), dim3(kBlock), 0, a);
 }
 
 
