@@ -232,6 +232,7 @@ def main():
             "dofs": nv, "cells": run.ne_global, "nnz": run.nnz_global,
             "newton_its": newton, "krylov_its": krylov,
             "krylov_its_per_newton": krylov / max(newton, 1),
+            "krylov_warm_start": run.ctx.get_params().krylov_warm_start, "krylov_newton_eta": run.ctx.get_params().krylov_newton_eta,
             "krylov": f"BiCGStab, right preconditioner {args.precond}; every linear solve runs until its TRUE residual is below "
                       f"max({args.krylov_rtol:g} ||F_k||, 0.1 x Newton's own stopping threshold max(1e-10, 1e-9 ||F_0||)) "
                       "(shk_params.krylov_newton_eta); "
