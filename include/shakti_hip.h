@@ -182,7 +182,11 @@ int shk_linear_solve(shk_ctx* ctx, int32_t* its, int32_t* converged, double* rel
 /* y = J x with the assembled Jacobian (unscaled) -- parity / roofline probe of the SpMV kernel. */
 int shk_spmv(shk_ctx* ctx, const double* x_host, double* y_host);
 
-/* NewtonSolver.solve(N) (solvers.py:179): updates SHK_N in place. */
+/* NewtonSolver.solve(N) (solvers.py:179): updates SHK_N in place.  Residual first, then per iteration J / linear solve /
+ * x <- x - dx / residual, converged at ||F|| < max(newton_atol, newton_rtol ||F_0||) (DOLFINx defaults).  Each linear
+ * solve runs to a TRUE residual of max(krylov_rtol ||F_k||, krylov_atol, krylov_newton_eta x that threshold) and starts
+ * from the projected solutions of the previous steps (krylov_warm_start); info reports Newton and Krylov counts, the
+ * worst true relative residual (krylov_relres) and whether a linear solve failed (krylov_failed). */
 int shk_newton_solve(shk_ctx* ctx, double dt, shk_solve_info* info);
 
 /* q, melt_n, b interpolations + clamp + N_n <- N (solvers.py:186-197,228-229). */
