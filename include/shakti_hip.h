@@ -145,8 +145,8 @@ int shk_comm_selftest(shk_ctx* ctx);
 /* Message rounds this context has issued since creation: n[0] ghost exchanges, n[1] all-reduces, n[2] bytes sent in
  * exchanges, n[3] bytes all-reduced (per rank).  Differences around a solve give rounds per Krylov iteration. */
 int shk_comm_stats(shk_ctx* ctx, int64_t n[4]);
-/* Interior / boundary split of the finest level's sweeps (several subdomains; default on with RCCL, off with the
- * host-staged callbacks, SHK_OVERLAP=0/1 overrides): the ghost
+/* Interior / boundary split of the finest level's sweeps (several subdomains; off unless the environment sets
+ * SHK_OVERLAP=1 -- DESIGN.md section 5 says why): the ghost
  * exchange of the two Krylov products and of the finest smoothing sweep travels on a second stream while the SELL
  * slices without ghost columns are swept; the others follow once it has arrived.  n[0] 1 = active, n[1] slices that
  * read ghost columns, n[2] all slices of the subdomain, n[3] exchanges issued this way since creation. */

@@ -917,10 +917,11 @@ static int comm_common(Ctx* c, int rank, int nranks, bool overlap_default) {
         c->np = 1;           // every subdomain reads the same all-reduced scalars
         c->red_stride = 1;
     }
-    // Interior / boundary overlap of the finest level's exchanges: on for RCCL, off for the host-staged transport, whose
-    // callback blocks the host anyway (measured with 2 subdomains sharing one GPU at 1M rows: 133 -> 183 ms per step
-    // with it; the hand-over to a second stream and back costs ~15 us, tools/probe_stream_handoff.py).  SHK_OVERLAP=0/1
-    // overrides either way.
+    // Interior / boundary overlap of the finest level's exchanges: OFF unless SHK_OVERLAP=1 asks for it.  Handing work to
+    // a second stream and back costs ~15 us on this machine (tools/probe_stream_handoff.py), as much as a small grouped
+    // send / recv is expected to take, and RCCL has never run with several ranks in this build's environment: the first
+    // multi-GPU runs should measure the plain path first.  (Host-staged transport, 2 subdomains sharing one GPU at 1M
+    // rows: 133 -> 183 ms per step with it -- the callback blocks the host anyway.)
     const bool want_overlap = getenv("SHK_OVERLAP") ? atoi(getenv("SHK_OVERLAP")) != 0 : overlap_default;
     if (nranks > 1 && want_overlap && !c->overlap) HIPCHK(overlap_setup(c));
     c->comm.rank = rank;
@@ -942,7 +943,7 @@ int shk_comm_init_rccl(shk_ctx* ctx, int32_t rank, int32_t nranks, const void* i
     if (c->comm.kind != Comm::NONE) return fail("communicator already initialised");
     HIPCHK(hipSetDevice(c->device));
     if (const char* e = rccl_load()) return fail(e);
-    if (comm_common(c, rank, nranks, true)) return -1;
+    if (comm_common(c, rank, nranks, false)) return -1;
     if (const char* e = rccl_init(c, rank, nranks, id128)) return fail(std::string("ncclCommInitRank: ") + e);
     return 0;
 }

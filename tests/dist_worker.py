@@ -83,8 +83,8 @@ def main():
             # margin covers the warm start, which shortens the later steps' solves by amounts that differ run to run)
             ok = ok and all(x[1] <= 1.5 * y[1] + 3 for x, y in zip(infos, ref_infos))
         ov = report["overlap"]
-        # default: on for RCCL, off for the host-staged transport; SHK_OVERLAP overrides
-        if world > 1 and os.environ.get("SHK_OVERLAP", "1" if a.transport == "rccl" else "0") != "0":
+        # off unless SHK_OVERLAP=1
+        if world > 1 and os.environ.get("SHK_OVERLAP", "0") != "0":
             # the level-0 exchanges travelled on the second stream behind an interior pass, over a genuine split
             ok = ok and ov["active"] and ov["overlapped_exchanges"] > 0 and 0 < ov["boundary_slices"] < ov["slices"]
         else:

@@ -17,8 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _launch(nproc, transport, port, extra=(), env_extra=None):
-    # SHK_OVERLAP=1: the gloo runs take the interior / boundary split that is the RCCL transport's default (the
-    # host-staged transport's own default is off), so every decomposition below exercises it
+    # SHK_OVERLAP=1: the runs below take the interior / boundary split of the finest level's exchanges (off by default),
+    # so every decomposition exercises it
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", **{"SHK_OVERLAP": "1", **(env_extra or {})})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"),
@@ -46,8 +46,7 @@ def test_partitioned_matches_single_at_1m_dof():
 
 
 def test_interior_boundary_overlap_changes_nothing_but_the_schedule():
-    """The interior / boundary split of the finest level's sweeps (shk_comm_overlap; the RCCL transport's default,
-    SHK_OVERLAP=1 here) against the serialised exchange (SHK_OVERLAP=0) on a 125k-DOF mesh over 3 subdomains: both match the
+    """The interior / boundary split of the finest level's sweeps (shk_comm_overlap, SHK_OVERLAP=1) against the serialised exchange (SHK_OVERLAP=0) on a 125k-DOF mesh over 3 subdomains: both match the
     undecomposed run to 1e-7 with its Newton counts, and their Krylov counts agree to within a few iterations (the split only
     changes the order in which partial sums of the dot products are added)."""
     reps = []
