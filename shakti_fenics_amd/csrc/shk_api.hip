@@ -65,6 +65,7 @@ static void derive_params(Ctx* c) {
     d.kcoef = p.g / (12.0 * p.nu);
     d.om_nu = p.omega / p.nu;
     d.ri_rw = p.rho_i / p.rho_w;
+    d.inv_rwg = 1.0 / d.rwg; d.inv_Lh = 1.0 / p.Lh; d.cm_Lh = d.c_m / p.Lh;
     d.n_is_3 = (p.n == 3.0) ? 1 : 0;
 }
 

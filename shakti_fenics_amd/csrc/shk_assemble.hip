@@ -8,8 +8,8 @@
 //            of patches: neighbouring patches then share an L2, which serves most halo gathers.
 //   phase 1  one thread per cell touching the owned rows (cells named by 3 x 16-bit LOCAL vertex ids: one coalesced
 //            8-byte load per cell, no dependent global gathers): 15-point degree-7 rule for the transmissivity
-//            integral, 7-point degree-5 rule for every polynomial term, both fully unrolled with their tables
-//            broadcast from LDS; the 3x3 + 3 element tensor stays in registers until every thread has read its
+//            integral, 7-point degree-5 rule for every polynomial term, both unrolled with their tables read as
+//            scalar kernel arguments; the 3x3 + 3 element tensor stays in registers until every thread has read its
 //            fields, then replaces them in the SAME LDS region (61 KB per workgroup instead of 100).
 //   phase 2  one thread per SELL slot: an off-diagonal entry adds its <= 2 staged cells named by the plan (4 B per
 //            slot, which also carries the slot's Dirichlet code), the diagonal and the residual row sum their
@@ -36,8 +36,10 @@ struct QPoint { double f0, f1, f2, w; };   // barycentric weights of a quadratur
 // Like FFCx, every coefficient is differenced on its own (reference gradient = nodal differences f1 - f0, f2 - f0):
 // rounding is then relative to the differences, not to the head's magnitude (~1e3 m over cells of ~10 m), which
 // puts the fp64 floor of ||F|| three orders of magnitude below what differencing nodal heads gives.
+// (Divisions by constants of the run -- rho_w g, Lh -- are multiplications by their reciprocals here: an fp64 division is
+//  a dozen instructions, a cell had thirteen of them, and the kernel is bound by fp64 issue.  One rounding differs.)
 __device__ __forceinline__ double head_diff(double dzb, double dzs, double dN, const DevParams& p) {
-    return dzb + p.ri_rw * (dzs - dzb) - dN / p.rwg;
+    return dzb + p.ri_rw * (dzs - dzb) - dN * p.inv_rwg;
 }
 
 // sqrt(s) for s >= 0 well inside the double range (|q|^2): rsq, one coupled Goldschmidt step and one residual
@@ -61,6 +63,13 @@ __device__ __forceinline__ double div_ge1(double a, double d) {
     return __builtin_fma(__builtin_fma(-d, q, a), r, q);
 }
 
+// 1 / d for |d| well inside the double range (twice a cell's area): rcp + two Newton steps.  ~1 ulp.
+__device__ __forceinline__ double rcp_nr(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    return __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+}
+
 // XCD-aware block map (MI355X: workgroups are dealt round-robin to 8 XCDs with private L2s): XCD x sweeps the
 // contiguous block range [start(x), start(x+1)).  Placement changes speed only.
 __device__ __forceinline__ int xcd_block(int b, int nb) {
@@ -79,7 +88,7 @@ __device__ __forceinline__ void cell_tensor(const AsmArgs& a, const double* __re
     const double x0 = LD(AF_X, l0), y0 = LD(AF_Y, l0);
     const double d1x = LD(AF_X, l1) - x0, d1y = LD(AF_Y, l1) - y0, d2x = LD(AF_X, l2) - x0, d2y = LD(AF_Y, l2) - y0;
     const double det = d1x * d2y - d1y * d2x;
-    const double inv = 1.0 / det;
+    const double inv = rcp_nr(det);
     const double area = 0.5 * fabs(det);
     const double g1x = d2y * inv, g1y = -d2x * inv, g2x = -d1y * inv, g2y = d1x * inv;
     const double g0x = -(g1x + g2x), g0y = -(g1y + g2y);
@@ -92,7 +101,10 @@ __device__ __forceinline__ void cell_tensor(const AsmArgs& a, const double* __re
     // (a P1 field at a quadrature point: f0 + (f1 - f0) phi1 + (f2 - f0) phi2 -- two FMAs per field and point)
     const double db1 = b1 - b0, db2 = b2 - b0, dqx1 = qx1 - qx0, dqx2 = qx2 - qx0, dqy1 = qy1 - qy0, dqy2 = qy2 - qy0;
     auto flux_point = [&](int k) {
-        const QPoint q = qk[k];
+        // built-in rule: k is a compile-time constant of the unrolled loop, so the point's weights come straight from the
+        // kernel arguments through scalar loads and enter the FMAs as SGPR operands -- no LDS read and no vector
+        // registers per point in flight (249 -> 201 VGPRs, -4 % time); a run-time table is broadcast from LDS
+        const QPoint q = NQ > 0 ? QPoint{0.0, a.quad.phi1[k], a.quad.phi2[k], a.quad.w2[k]} : qk[k];
         const double bk = __builtin_fma(db2, q.f2, __builtin_fma(db1, q.f1, b0));
         const double qxk = __builtin_fma(dqx2, q.f2, __builtin_fma(dqx1, q.f1, qx0));
         const double qyk = __builtin_fma(dqy2, q.f2, __builtin_fma(dqy1, q.f1, qy0));
@@ -117,7 +129,7 @@ __device__ __forceinline__ void cell_tensor(const AsmArgs& a, const double* __re
     const double gbx = db1 * g1x + db2 * g2x, gby = db1 * g1y + db2 * g2y;
     const double gmx = (m1_ - m0_) * g1x + (m2_ - m0_) * g2x, gmy = (m1_ - m0_) * g1y + (m2_ - m0_) * g2y;
     const double gb2 = gbx * gbx + gby * gby;
-    const double inv_den = 1.0 / (1.0 + gb2);
+    const double inv_den = div_ge1(1.0, 1.0 + gb2);
     const double gmgb = gmx * gbx + gmy * gby;
     const double Nn0 = LD(AF_NN, l0), Nn1 = LD(AF_NN, l1), Nn2 = LD(AF_NN, l2);
     const double G0 = LD(AF_G, l0), G1 = LD(AF_G, l1), G2 = LD(AF_G, l2);
@@ -133,7 +145,7 @@ __device__ __forceinline__ void cell_tensor(const AsmArgs& a, const double* __re
     const double dm1 = m1_ - m0_, dm2 = m2_ - m0_, ds1 = s1 - s0, ds2 = s2 - s0, di1 = i1 - i0, di2 = i2 - i0;
     const double dg1 = qgh1 - qgh0, dg2 = qgh2 - qgh0;
     auto poly_point = [&](int k) {
-        const QPoint q = qp[k];
+        const QPoint q = NP > 0 ? QPoint{a.qpoly.phi0[k], a.qpoly.phi1[k], a.qpoly.phi2[k], a.qpoly.w2[k]} : qp[k];
         const double f0 = q.f0, f1 = q.f1, f2 = q.f2;
         const double w = q.w * area;
         const double Nk = __builtin_fma(dN2, f2, __builtin_fma(dN1, f1, N0));
@@ -145,7 +157,7 @@ __device__ __forceinline__ void cell_tensor(const AsmArgs& a, const double* __re
         const double ik = __builtin_fma(di2, f2, __builtin_fma(di1, f1, i0));
         const double qghk = __builtin_fma(dg2, f2, __builtin_fma(dg1, f1, qgh0));
         // Melt, constitutive.py:22-27 (div of the cell-wise P1 product expanded)
-        const double melt = (Gk - qghk) / p.Lh + (mk * gb2 + bk * gmgb) * inv_den;
+        const double melt = (Gk - qghk) * p.inv_Lh + (mk * gb2 + bk * gmgb) * inv_den;
         const double pw = p.n_is_3 ? Nk * Nk : pow(fabs(Nk), p.n - 1.0);   // |N|^(n-1), constitutive.py:31
         const double closure = p.A * bk * Nk * pw;                 // constitutive.py:29-31
         const double stor = sk * (Nk - Nnk) * a.inv_rwg_dt;        // solvers.py:42
@@ -165,11 +177,11 @@ __device__ __forceinline__ void cell_tensor(const AsmArgs& a, const double* __re
     double Fe0 = sK * (ghx * g0x + ghy * g0y) + F0;
     double Fe1 = sK * (ghx * g1x + ghy * g1y) + F1;
     double Fe2 = sK * (ghx * g2x + ghy * g2y) + F2;
-    const double kk = -sK / p.rwg;
+    const double kk = -sK * p.inv_rwg;
     const double d00 = g0x * g0x + g0y * g0y, d01 = g0x * g1x + g0y * g1y, d02 = g0x * g2x + g0y * g2y;
     const double d11 = g1x * g1x + g1y * g1y, d12 = g1x * g2x + g1y * g2y, d22 = g2x * g2x + g2y * g2y;
     // int phi_i q_x dx = area/12 (sum q_x + q_x,i): exact P1 mass matrix
-    const double cq = p.c_m / p.Lh * area * (1.0 / 12.0);
+    const double cq = p.cm_Lh * area * (1.0 / 12.0);
     const double sx = qx0 + qx1 + qx2, sy = qy0 + qy1 + qy2;
     const double Px0 = cq * (sx + qx0), Px1 = cq * (sx + qx1), Px2 = cq * (sx + qx2);
     const double Py0 = cq * (sy + qy0), Py1 = cq * (sy + qy1), Py2 = cq * (sy + qy2);
@@ -231,10 +243,12 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
     for (int i = tid; i <= ns; i += T) sp[i] = a.A.ptr[s0 + i];
     for (int i = tid; i <= nrows; i += T) ip[i] = a.incptr[r0 + i];
     for (int i = tid; i < ninc; i += T) ic[i] = a.inccode[ip0 + i];
-    if (tid < a.quad.nq) qk[tid] = QPoint{a.quad.phi0[tid], a.quad.phi1[tid], a.quad.phi2[tid], a.quad.w2[tid]};
-    if (tid >= 64 && tid - 64 < a.qpoly.nq) {
-        const int k = tid - 64;
-        qp[k] = QPoint{a.qpoly.phi0[k], a.qpoly.phi1[k], a.qpoly.phi2[k], a.qpoly.w2[k]};
+    if constexpr (NQ == 0 || NP == 0) {   // run-time rules only: the built-in ones are read as scalar arguments
+        if (tid < a.quad.nq) qk[tid] = QPoint{a.quad.phi0[tid], a.quad.phi1[tid], a.quad.phi2[tid], a.quad.w2[tid]};
+        if (tid >= 64 && tid - 64 < a.qpoly.nq) {
+            const int k = tid - 64;
+            qp[k] = QPoint{a.qpoly.phi0[k], a.qpoly.phi1[k], a.qpoly.phi2[k], a.qpoly.w2[k]};
+        }
     }
     // (all global loads of a thread -- its own row and up to kHaloPer halo vertices -- are issued before the first LDS
     //  write, so their latencies overlap instead of adding up)
@@ -286,7 +300,8 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
     }
     // the plan words of this thread's slots (phase 2) are requested here -- after the element computation, whose
     // registers they would otherwise crowd (they cost 80 B per lane of scratch spills = 0.8 GB of traffic per pass when
-    // requested at kernel start) -- and arrive while the tensors go to LDS
+    // requested at kernel start; with the 48 registers the scalar quadrature tables freed, still 1.74 against 1.70 ms)
+    // -- and arrive while the tensors go to LDS
     constexpr int kSlotIt = (kAsmSlotsMax + T - 1) / T;
     uint32_t srcw[kSlotIt];
 #pragma unroll

@@ -26,6 +26,7 @@ struct DevParams {
     double kcoef;    // g / (12 nu)
     double om_nu;    // omega / nu
     double ri_rw;    // rho_i / rho_w
+    double inv_rwg, inv_Lh, cm_Lh;   // 1 / (rho_w g), 1 / Lh, c_m / Lh: the assembly multiplies where the forms divide
     int n_is_3;
 };
 
