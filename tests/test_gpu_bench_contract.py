@@ -30,6 +30,10 @@ def test_bench_line_has_every_contract_field():
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
     assert roof["traffic"] is None and "traffic_source" in roof      # no counter file for this configuration
+    whole = roof["whole_iterations"]                                 # whole Krylov / Newton iterations
+    assert whole["krylov_iteration"]["algorithmic_bytes"] == 416 * d["config"]["dofs"]
+    assert 0 < whole["krylov_iteration"]["frac"] < 1 and 0 < whole["newton_iteration"]["frac"] < 1
+    assert d["config"]["krylov_warm_start"] == 4 and d["config"]["krylov_newton_eta"] == 0.1
     cpu = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cpu
