@@ -35,9 +35,15 @@ namespace shk {
 template <class TC, int ILP>
 __global__ __launch_bounds__(kBlock) void k_galerkin(int64_t nslots, const int32_t* __restrict__ gptr,
                                                      const int32_t* __restrict__ glist,
-                                                     const float* __restrict__ fine, TC* __restrict__ coarse) {
+                                                     const float* __restrict__ fine, TC* __restrict__ coarse, int contiguous) {
     constexpr int64_t kChunk = (int64_t)ILP * kBlock;
-    for (int64_t c0 = blockIdx.x * kChunk; c0 < nslots; c0 += (int64_t)gridDim.x * kChunk) {
+    // contiguous: a workgroup walks ONE run of consecutive slots (the k-columns of a few coarse slices, whose lists share
+    // fine cache lines) instead of striding through the whole array
+    const int64_t nchunk = (nslots + kChunk - 1) / kChunk, per = (nchunk + gridDim.x - 1) / gridDim.x;
+    const int64_t first = contiguous ? blockIdx.x * per * kChunk : blockIdx.x * kChunk;
+    const int64_t last = contiguous ? min(nslots, (blockIdx.x + 1) * per * kChunk) : nslots;
+    const int64_t stride = contiguous ? kChunk : (int64_t)gridDim.x * kChunk;
+    for (int64_t c0 = first; c0 < last; c0 += stride) {
         int32_t b[ILP], e[ILP];
         double a[ILP];
         int len = 0;
@@ -83,11 +89,13 @@ template <class TC>
 static void launch_galerkin(Ctx* c, int kind, int64_t nslots, const int32_t* gptr, const int32_t* glist, const float* fine, TC* coarse) {
     static const int ilp_env[2] = {getenv("SHK_GAL_ILP0") ? atoi(getenv("SHK_GAL_ILP0")) : 1, getenv("SHK_GAL_ILP1") ? atoi(getenv("SHK_GAL_ILP1")) : 4};
     static const int grid_env[2] = {getenv("SHK_GAL_GRID0") ? atoi(getenv("SHK_GAL_GRID0")) : 1024, getenv("SHK_GAL_GRID1") ? atoi(getenv("SHK_GAL_GRID1")) : 2048};
+    static const int contig_env[2] = {getenv("SHK_GAL_CONTIG0") ? atoi(getenv("SHK_GAL_CONTIG0")) : 1, getenv("SHK_GAL_CONTIG1") ? atoi(getenv("SHK_GAL_CONTIG1")) : 0};
+    const int contig = contig_env[kind];
     const int ilp = ilp_env[kind];
     const int g = (int)std::min<int64_t>(grid_env[kind], std::max<int64_t>(1, (nslots + (int64_t)ilp * kBlock - 1) / ((int64_t)ilp * kBlock)));
-    if (ilp == 4) hipLaunchKernelGGL((k_galerkin<TC, 4>), dim3(g), dim3(kBlock), 0, c->stream, nslots, gptr, glist, fine, coarse);
-    else if (ilp == 2) hipLaunchKernelGGL((k_galerkin<TC, 2>), dim3(g), dim3(kBlock), 0, c->stream, nslots, gptr, glist, fine, coarse);
-    else hipLaunchKernelGGL((k_galerkin<TC, 1>), dim3(g), dim3(kBlock), 0, c->stream, nslots, gptr, glist, fine, coarse);
+    if (ilp == 4) hipLaunchKernelGGL((k_galerkin<TC, 4>), dim3(g), dim3(kBlock), 0, c->stream, nslots, gptr, glist, fine, coarse, contig);
+    else if (ilp == 2) hipLaunchKernelGGL((k_galerkin<TC, 2>), dim3(g), dim3(kBlock), 0, c->stream, nslots, gptr, glist, fine, coarse, contig);
+    else hipLaunchKernelGGL((k_galerkin<TC, 1>), dim3(g), dim3(kBlock), 0, c->stream, nslots, gptr, glist, fine, coarse, contig);
 }
 
 __global__ __launch_bounds__(kBlock) void k_diag_inv(int32_t n, const int32_t* __restrict__ diag_slot,
@@ -1453,6 +1461,8 @@ int amg_setup_distributed(Ctx* c, std::string& err) {
         if ((e = amg_upload_rep_top(c, *H.rep, G, G_diag)) != hipSuccess ||
             (e = amg_upload(c, rplans, *H.rep, G.n_rows, &ident)) != hipSuccess) { err = hipGetErrorString(e); return -1; }
     }
+    // (amg_upload zero-fills on the null stream; the cycles run on the context's non-blocking stream)
+    if (hipDeviceSynchronize() != hipSuccess) { err = "synchronize"; return -1; }
     return 0;
 }
 

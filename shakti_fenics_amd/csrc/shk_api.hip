@@ -384,6 +384,8 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
             if ((e = hipMemset(*v, 0, nl * sizeof(float))) != hipSuccess) return bail(e, "memset");
         }
     }
+    // the zero fills above ran on the null stream, which the context's non-blocking stream is not ordered with
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return bail(e, "synchronize");
     *out = reinterpret_cast<shk_ctx*>(c);
     return 0;
 }
@@ -600,27 +602,41 @@ static int krylov_inner(Ctx* c, const double* rhs, int max_it, KrylovState* out)
     int it = 0, slot = 0;
     const int saved_max = c->params.krylov_max_it;
     c->params.krylov_max_it = max_it;
-    auto enqueue = [&](int sl) -> hipError_t {
+    auto enqueue = [&](int sl, int n) -> hipError_t {
         hipError_t e = hipSuccess;
-        for (int k = 0; k < chunk; ++k)
+        for (int k = 0; k < n; ++k)
             if ((e = krylov_iteration(c, it + k)) != hipSuccess) return e;
-        it += chunk;
+        it += n;
         e = hipMemcpyAsync(&c->h_state[sl], c->d_state, sizeof(KrylovState), hipMemcpyDeviceToHost,
                                       c->stream);
         if (e != hipSuccess) return e;
         return hipEventRecord(c->poll_ev[sl], c->stream);
     };
-    hipError_t e = enqueue(slot);
+    hipError_t e = enqueue(slot, chunk);
     int rc = 0;
     // (profiling uses the same pipelined polling: with the queue kept full the per-launch event durations agree
     // with a rocprofv3 trace -- a GPU left idle between iterations runs every kernel ~10 % slower -- and the launches
     // that return at once behind the stop flag are dropped when the events are read)
+    // Far from the target the next chunk is queued before the previous one's flag is read (the GPU never waits for the
+    // host); everything queued behind the stop costs ~90 empty launches per iteration, so within a factor kNear of the
+    // target (||r||, from the state the poll copies anyway) the loop queues one iteration at a time and waits for it:
+    // a host round trip per iteration for the last few instead of 2-4 iterations of empty launches per solve.
+    static const double near2 = getenv("SHK_KRYLOV_NEAR") ? std::pow(atof(getenv("SHK_KRYLOV_NEAR")), 2) : 100.0;
+    bool careful = false;
     while (e == hipSuccess) {
-        const int prev = slot;
-        slot ^= 1;
-        if ((e = enqueue(slot)) != hipSuccess) break;
-        if ((e = wait_event(c, c->poll_ev[prev])) != hipSuccess) break;
-        if (c->h_state[prev].done) { *out = c->h_state[prev]; break; }
+        if (!careful) {
+            const int prev = slot;
+            slot ^= 1;
+            if ((e = enqueue(slot, chunk)) != hipSuccess) break;
+            if ((e = wait_event(c, c->poll_ev[prev])) != hipSuccess) break;
+            const KrylovState& st = c->h_state[prev];
+            if (st.done) { *out = st; break; }
+            careful = near2 > 0.0 && st.target2 > 0.0 && st.rr_last <= near2 * st.target2;
+        } else {
+            if ((e = wait_event(c, c->poll_ev[slot])) != hipSuccess) break;
+            if (c->h_state[slot].done) { *out = c->h_state[slot]; break; }
+            if ((e = enqueue(slot, 1)) != hipSuccess) break;
+        }
         if (it > max_it + 4 * chunk) { rc = fail("Krylov driver ran past max_it without a stop flag"); break; }
     }
     c->params.krylov_max_it = saved_max;
@@ -648,13 +664,15 @@ static int read_aux_norm(Ctx* c, double* out) {  // fixed-order host sum of the 
 static int warm_alloc(Ctx* c, int newton_it) {
     if (!c->d_part_w) {
         HIPCHK(dev_alloc(c, &c->d_part_w, (size_t)Ctx::kWarmDots * kMaxParts));
-        HIPCHK(hipMemset(c->d_part_w, 0, (size_t)Ctx::kWarmDots * kMaxParts * sizeof(double)));
+        // (on the context's stream: it is a non-blocking stream, which a null-stream hipMemset would NOT be ordered with --
+        //  the copy that follows could be overtaken by the zeroing)
+        HIPCHK(hipMemsetAsync(c->d_part_w, 0, (size_t)Ctx::kWarmDots * kMaxParts * sizeof(double), c->stream));
         HIPCHK(dev_alloc(c, &c->d_red_w, (size_t)Ctx::kWarmDots));
     }
     for (int j = 0; j < Ctx::kWarmDepth; ++j)
         if (!c->d_guess[newton_it][j]) {
             HIPCHK(dev_alloc(c, &c->d_guess[newton_it][j], (size_t)c->n_loc));
-            HIPCHK(hipMemset(c->d_guess[newton_it][j], 0, (size_t)c->n_loc * sizeof(double)));
+            HIPCHK(hipMemsetAsync(c->d_guess[newton_it][j], 0, (size_t)c->n_loc * sizeof(double), c->stream));
         }
     return 0;
 }
@@ -897,7 +915,7 @@ static hipError_t overlap_setup(Ctx* c) {
     if ((e = upload(c, &c->d_bslices, list)) != hipSuccess) return e;
     c->n_bslices = (int)list.size();
     if ((e = dev_alloc(c, &c->d_part_b, (size_t)P_COUNT * kMaxParts)) != hipSuccess) return e;
-    if ((e = hipMemset(c->d_part_b, 0, (size_t)P_COUNT * kMaxParts * sizeof(double))) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(c->d_part_b, 0, (size_t)P_COUNT * kMaxParts * sizeof(double), c->stream)) != hipSuccess) return e;
     if ((e = hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking)) != hipSuccess) return e;
     if ((e = hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming)) != hipSuccess) return e;
     if ((e = hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming)) != hipSuccess) return e;
@@ -913,7 +931,7 @@ static int comm_common(Ctx* c, int rank, int nranks, bool overlap_default) {
     if (nranks > 1 && c->d_red == c->d_part) {
         double* red = nullptr;
         if (dev_alloc(c, &red, (size_t)P_COUNT) != hipSuccess) return fail("alloc reduced scalars");
-        HIPCHK(hipMemset(red, 0, (size_t)P_COUNT * sizeof(double)));
+        HIPCHK(hipMemsetAsync(red, 0, (size_t)P_COUNT * sizeof(double), c->stream));
         c->d_red = red;
         c->np = 1;           // every subdomain reads the same all-reduced scalars
         c->red_stride = 1;

@@ -44,6 +44,7 @@ struct KrylovState {
     double target2;     // squared stopping threshold
     double rnorm2;      // ||r||^2 at exit
     double rhs2;        // ||rhs||^2
+    double rr_last;     // ||r||^2 seen by the latest stop test (the host reads it to stop queueing ahead near the target)
     int done;           // 1 once converged / stopped; later kernels return immediately
     int converged;
     int breakdown;

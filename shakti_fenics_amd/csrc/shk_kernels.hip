@@ -273,7 +273,7 @@ __global__ __launch_bounds__(kBlock) void k_bicg_init(int64_t n, const double* _
         part[P_RR * kMaxParts + blockIdx.x] = a;
         if (blockIdx.x == 0) {
             st->rho[0] = 0.0; st->rho[1] = 0.0; st->alpha = 0.0; st->omega = 0.0;
-            st->target2 = 0.0; st->rnorm2 = 0.0; st->rhs2 = 0.0;
+            st->target2 = 0.0; st->rnorm2 = 0.0; st->rhs2 = 0.0; st->rr_last = 0.0;
             st->done = 0; st->converged = 0; st->breakdown = 0; st->its = 0;
         }
     }
@@ -295,6 +295,7 @@ __global__ __launch_bounds__(kBlock) void k_bicg_s(int64_t n, int it, int max_it
     const double target2 = (it == 0) ? fmax(rtol2 * rr, atol2) : st->target2;
     const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
     if (lead && it == 0) { st->target2 = target2; st->rhs2 = rr; st->rho[0] = rr; }
+    if (lead) st->rr_last = rr;
     int stop = 0, conv = 0;
     if (!(rr > target2)) { stop = 1; conv = (rr <= target2); }  // also stops on NaN
     else if (it >= max_it) stop = 1;
