@@ -617,11 +617,13 @@ static int krylov_inner(Ctx* c, const double* rhs, int max_it, KrylovState* out)
     // (profiling uses the same pipelined polling: with the queue kept full the per-launch event durations agree
     // with a rocprofv3 trace -- a GPU left idle between iterations runs every kernel ~10 % slower -- and the launches
     // that return at once behind the stop flag are dropped when the events are read)
-    // Far from the target the next chunk is queued before the previous one's flag is read (the GPU never waits for the
-    // host); everything queued behind the stop costs ~90 empty launches per iteration, so within a factor kNear of the
-    // target (||r||, from the state the poll copies anyway) the loop queues one iteration at a time and waits for it:
-    // a host round trip per iteration for the last few instead of 2-4 iterations of empty launches per solve.
-    static const double near2 = getenv("SHK_KRYLOV_NEAR") ? std::pow(atof(getenv("SHK_KRYLOV_NEAR")), 2) : 100.0;
+    // The next chunk is queued before the previous one's flag is read (the GPU never waits for the host); everything
+    // queued behind the stop costs ~90 empty launches per iteration.  SHK_KRYLOV_NEAR=f (experiment, off by default) stops
+    // queueing ahead once ||r|| is within a factor f of the target and then waits for every iteration: measured at 10M DOF
+    // with f = 10, 58.4 -> 57.5 ms per step, but the GPU idles during those round trips and every kernel launched after an
+    // idle gap runs slower (k_spmv 165 -> 188 us on average over the step, the smoothers alike) -- the launches saved are
+    // paid back in kernel time, and the per-kernel figures of the bench line stop describing the kernels.
+    static const double near2 = getenv("SHK_KRYLOV_NEAR") ? std::pow(atof(getenv("SHK_KRYLOV_NEAR")), 2) : 0.0;
     bool careful = false;
     while (e == hipSuccess) {
         if (!careful) {
