@@ -922,7 +922,7 @@ static hipError_t overlap_setup(Ctx* c) {
     if ((e = hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming)) != hipSuccess) return e;
     if ((e = hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming)) != hipSuccess) return e;
     c->overlap = true;
-    return hipSuccess;
+    return hipDeviceSynchronize();   // the uploads above used the null stream, the sweeps use the context's
 }
 
 static int comm_common(Ctx* c, int rank, int nranks, bool overlap_default) {
