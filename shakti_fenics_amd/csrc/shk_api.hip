@@ -513,7 +513,9 @@ int shk_set_dirichlet(shk_ctx* ctx, int64_t n, const int32_t* dofs, double value
         if (dofs[i] < 0 || dofs[i] >= c->n_loc) return fail("Dirichlet dof outside [0, nv)");
         flag[c->plan.iperm[dofs[i]]] = 1;
     }
-    HIPCHK(hipMemcpy(c->d_bcflag, flag.data(), (size_t)c->n_loc, hipMemcpyHostToDevice));
+    // on the context's stream (behind whatever still reads the old flags; the stream is non-blocking, so a null-stream
+    // copy would be ordered with nothing); `flag` lives until the synchronisation below
+    HIPCHK(hipMemcpyAsync(c->d_bcflag, flag.data(), (size_t)c->n_loc, hipMemcpyHostToDevice, c->stream));
     launch_slot_bc(c);   // per-slot Dirichlet codes into the plan words (all zero when n == 0)
     HIPCHK(hipStreamSynchronize(c->stream));
     c->has_bc = n > 0;
@@ -891,6 +893,7 @@ int shk_set_halo(shk_ctx* ctx, int32_t n_nbr, const int32_t* nbr_rank, const int
     if (dev_alloc(c, &m.d_recvbuf, (size_t)nrecv) != hipSuccess) return fail("halo alloc");
     if (nsend > 0)
         HIPCHK(hipMemcpy(P.d_send_idx, P.h_send_idx.data(), (size_t)nsend * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipDeviceSynchronize());   // null-stream upload, used from the context's (non-blocking) stream
     HIPCHK(hipHostMalloc((void**)&m.h_send, std::max<size_t>(1, (size_t)nsend) * sizeof(double)));
     HIPCHK(hipHostMalloc((void**)&m.h_recv, std::max<size_t>(1, (size_t)nrecv) * sizeof(double)));
     m.h_red_cap = (size_t)P_COUNT * kMaxParts;
