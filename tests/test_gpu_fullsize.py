@@ -134,3 +134,22 @@ def test_step_is_reproducible_and_keeps_its_invariants(big):
     # a fresh assembly at the converged state reproduces the residual Newton reported (first step of the next solve)
     c.assemble(DT)
     assert np.isfinite(np.linalg.norm(c.residual()))
+
+
+def test_two_fresh_contexts_take_identical_paths_at_10m_dof():
+    """Run-to-run determinism of the whole solve loop with the warm-started linear solves ON, at the size where host and
+    device timing differ most: two fresh contexts on the 10M-DOF mesh, six steps each, must report identical Newton and
+    Krylov counts at every step and bit-identical fields (fixed summation orders, no atomics, every buffer's zero fill
+    ordered with the stream that uses it -- a null-stream fill once overtook the copy of a kept solution here)."""
+    from shakti_fenics_amd.runner import SingleRunner
+    runs = []
+    for _ in range(2):
+        r = SingleRunner("c4_10m")
+        counts = []
+        for i in range(6):
+            info = r.step(i)
+            counts.append((info.newton_its, info.krylov_its))
+        runs.append((counts, r.ctx.get_field("N"), r.ctx.get_field("b")))
+        r.close()
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    assert np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
