@@ -96,8 +96,15 @@ typedef struct shk_solve_info {
 enum shk_phase {
     SHK_PH_ASSEMBLE = 0, SHK_PH_SPMV = 1, SHK_PH_VECTOR = 2, SHK_PH_UPDATE = 3, SHK_PH_OTHER = 4,
     SHK_PH_HALO = 5, SHK_PH_AMG_FINE = 6 /* finest-level smoothing SpMV, k_amg_post<true> */,
-    SHK_PH_AMG_COARSE = 7 /* every other multigrid kernel */,
-    SHK_PH_AMG_FIRST = 8 /* finest-level first sweep on the A*P operator, k_amg_first<true> */, SHK_PH_COUNT = 9
+    SHK_PH_AMG_COARSE = 7 /* multigrid kernels not named below (prolongations, gathers, the one-workgroup tail) */,
+    SHK_PH_AMG_FIRST = 8 /* finest-level first sweep on the A*P operator, k_amg_first<true> */,
+    SHK_PH_AMG_REP = 9 /* every kernel of the REPLICATED coarse hierarchy of a decomposed mesh: the part of a cycle
+                          that does not shrink with the number of GPUs */,
+    SHK_PH_AMG_RESTRICT = 10 /* the restrictions of the way down */,
+    SHK_PH_AMG_DENSE = 11 /* the dense coarsest solve (GEMV with the kept inverse) */,
+    SHK_PH_AMG_L1 = 12 /* the smoothing sweeps of coarse level 1; level l is SHK_PH_AMG_L1 + l - 1, levels >= 8 share
+                          the last slot */,
+    SHK_PH_AMG_L8 = 19, SHK_PH_COUNT = 20
 };
 typedef struct shk_profile {
     double ms[SHK_PH_COUNT];      /* summed launch durations per phase */
@@ -142,6 +149,17 @@ int shk_comm_init_callbacks(shk_ctx* ctx, int32_t rank, int32_t nranks, shk_exch
  * ncclRecv to the rank itself on the context's stream and again on a second, event-ordered stream, ncclAllReduce,
  * async-error query); 0 = passed. */
 int shk_comm_selftest(shk_ctx* ctx);
+/* Timing-only transport (measurement aid, any transport, AFTER the collective setup): with on != 0 every ghost
+ * exchange and reduction across subdomains returns at once -- pack / unpack kernels still run, the message itself is
+ * skipped, ghosts keep stale values and reductions stay local.  RESULTS ARE WRONG BY CONSTRUCTION, kernel durations are
+ * those of the subdomain: one rank of a P-way decomposition can be timed alone on one GPU (tools/scaling_model.py).
+ * shk_step / shk_newton_solve report what they computed; nothing in the product path turns this on. */
+int shk_comm_set_timing_only(shk_ctx* ctx, int32_t on);
+/* What the RCCL deadline does when it fires, exposed for hosts that detect a dead peer themselves (and for tests): marks
+ * the context POISONED.  Every later call that would wait for the device fails at once, and shk_destroy returns without
+ * synchronising, destroying the communicator (ncclCommAbort if available) or freeing device memory -- all of which
+ * would block behind the stalled collective.  The process is expected to exit non-zero right after. */
+int shk_comm_mark_stalled(shk_ctx* ctx);
 /* Message rounds this context has issued since creation: n[0] ghost exchanges, n[1] all-reduces, n[2] bytes sent in
  * exchanges, n[3] bytes all-reduced (per rank).  Differences around a solve give rounds per Krylov iteration. */
 int shk_comm_stats(shk_ctx* ctx, int64_t n[4]);
@@ -153,6 +171,12 @@ int shk_comm_stats(shk_ctx* ctx, int64_t n[4]);
 int shk_comm_overlap(shk_ctx* ctx, int64_t n[4]);
 /* Refresh the ghost entries of a field from their owners (scatter_forward, solvers.py:197,229). */
 int shk_halo_update(shk_ctx* ctx, int32_t field);
+
+/* Experiment switches: every SHK_* environment variable the library honours is read once per process
+ * (csrc/shk_tunables.h).  Copies "NAME=value, ..." of the ones that are SET into buf (NUL-terminated, truncated to cap)
+ * and returns how many there are; 0 = the run uses the defaults every committed measurement was taken with.  None of
+ * them changes what is computed.  buf may be NULL. */
+int64_t shk_env_overrides(char* buf, int64_t cap);
 
 int shk_default_params(shk_params* p);
 int shk_set_params(shk_ctx* ctx, const shk_params* p);

@@ -19,6 +19,21 @@ class ShaktiHipError(RuntimeError):
     pass
 
 
+class ShaktiCommStall(ShaktiHipError):
+    """A host wait hit the RCCL deadline: the context is poisoned (its stream will never drain).  The only sane
+    continuation is to exit the process non-zero so that the launcher tears the job down: `exit_on_stall`."""
+
+
+def exit_on_stall(exc: BaseException):
+    """Report a communication stall and leave the process at once with status 1 (no atexit handlers, no destructors:
+    anything that waits for the device would hang behind the stalled collective)."""
+    import sys
+    import traceback
+    traceback.print_exception(type(exc), exc, exc.__traceback__, file=sys.stderr)
+    print("[shakti_fenics_amd] communication stall: exiting with status 1", file=sys.stderr, flush=True)
+    os._exit(1)
+
+
 class shk_params(C.Structure):
     _fields_ = [(n, C.c_double) for n in
                 ("g", "rho_i", "rho_w", "nu", "Lh", "omega", "n", "A", "b_min",
@@ -32,7 +47,10 @@ class shk_solve_info(C.Structure):
                 ("krylov_relres", C.c_double)]
 
 
-PHASES = ("assemble", "spmv", "vector", "update", "other", "halo", "amg_fine", "amg_coarse", "amg_first")
+PHASES = ("assemble", "spmv", "vector", "update", "other", "halo", "amg_fine", "amg_other", "amg_first", "amg_rep",
+          "amg_restrict", "amg_dense") + tuple(f"amg_l{l}" for l in range(1, 9))
+# phases that make up what rounds 1-2 reported as "amg_coarse" (every multigrid kernel below the finest level)
+COARSE_PHASES = ("amg_other", "amg_rep", "amg_restrict", "amg_dense") + tuple(f"amg_l{l}" for l in range(1, 9))
 PRECOND = dict(jacobi=0, amg=1, amg_local=2)
 
 
@@ -49,7 +67,7 @@ EXPORTS = (
     "shk_assemble", "shk_get_residual", "shk_csr_nnz", "shk_get_csr", "shk_linear_solve", "shk_spmv",
     "shk_newton_solve", "shk_update_explicit", "shk_step", "shk_sync", "shk_profile_enable",
     "shk_profile_read", "shk_time_kernel", "shk_plan_stats", "shk_set_halo", "shk_comm_unique_id",
-    "shk_comm_init_rccl", "shk_comm_init_callbacks", "shk_comm_selftest", "shk_comm_stats", "shk_comm_overlap", "shk_halo_update", "shk_interp_regular_grid",
+    "shk_comm_init_rccl", "shk_comm_init_callbacks", "shk_comm_selftest", "shk_comm_set_timing_only", "shk_comm_mark_stalled", "shk_env_overrides", "shk_comm_stats", "shk_comm_overlap", "shk_halo_update", "shk_interp_regular_grid",
     "shk_points_in_polygon",
 )
 
@@ -107,6 +125,9 @@ def load():
         "shk_comm_stats": ([vp, P(i64)], C.c_int),
         "shk_comm_overlap": ([vp, P(i64)], C.c_int),
         "shk_comm_selftest": ([vp], C.c_int),
+        "shk_comm_set_timing_only": ([vp, i32], C.c_int),
+        "shk_comm_mark_stalled": ([vp], C.c_int),
+        "shk_env_overrides": ([C.c_char_p, i64], i64),
         "shk_interp_regular_grid": ([C.c_int, i64, vp, vp, i64, i64, vp, vp, vp, i32, vp], C.c_int),
         "shk_points_in_polygon": ([C.c_int, i64, vp, vp, i64, vp, vp], C.c_int),
     }
@@ -116,6 +137,13 @@ def load():
         fn.restype = res
     _lib = lib
     return lib
+
+
+def env_overrides() -> str:
+    """The SHK_* experiment switches set in the environment ("" = defaults), as the library read them."""
+    buf = C.create_string_buffer(4096)
+    load().shk_env_overrides(buf, 4096)
+    return buf.value.decode()
 
 
 def rccl_unique_id() -> bytes:
@@ -207,7 +235,8 @@ class ShaktiHip:
 
     def _check(self, rc):
         if rc != 0:
-            raise ShaktiHipError(self.lib.shk_last_error().decode())
+            msg = self.lib.shk_last_error().decode()
+            raise (ShaktiCommStall if "stream stalled" in msg else ShaktiHipError)(msg)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -351,6 +380,13 @@ class ShaktiHip:
     def comm_selftest(self):
         self._check(self.lib.shk_comm_selftest(self._h))
 
+    def comm_set_timing_only(self, on: bool):
+        """Measurement aid (tools/scaling_model.py): messages are skipped, results become wrong, durations stay right."""
+        self._check(self.lib.shk_comm_set_timing_only(self._h, 1 if on else 0))
+
+    def comm_mark_stalled(self):
+        self._check(self.lib.shk_comm_mark_stalled(self._h))
+
     def comm_stats(self) -> dict:
         n = (C.c_int64 * 4)()
         self._check(self.lib.shk_comm_stats(self._h, n))
@@ -372,7 +408,10 @@ class ShaktiHip:
     def profile_read(self, reset: bool = True) -> dict:
         p = shk_profile()
         self._check(self.lib.shk_profile_read(self._h, C.byref(p), 1 if reset else 0))
-        return {name: dict(ms=p.ms[i], launches=p.launches[i]) for i, name in enumerate(PHASES)}
+        out = {name: dict(ms=p.ms[i], launches=p.launches[i]) for i, name in enumerate(PHASES)}
+        # every multigrid kernel below the finest level, as one figure (what rounds 1-2 called amg_coarse)
+        out["amg_coarse"] = dict(ms=sum(out[k]["ms"] for k in COARSE_PHASES), launches=sum(out[k]["launches"] for k in COARSE_PHASES))
+        return out
 
     def time_kernel(self, phase: str, reps: int, dt: float = 3600.0) -> float:
         ms = C.c_double()

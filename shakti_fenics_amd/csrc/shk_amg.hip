@@ -87,12 +87,10 @@ __global__ __launch_bounds__(kBlock) void k_galerkin(int64_t nslots, const int32
 // kind 0: a coarse operator P^T A P (long, uneven lists), kind 1: A*P (1-2 entries per slot)
 template <class TC>
 static void launch_galerkin(Ctx* c, int kind, int64_t nslots, const int32_t* gptr, const int32_t* glist, const float* fine, TC* coarse) {
-    static const int ilp_env[2] = {getenv("SHK_GAL_ILP0") ? atoi(getenv("SHK_GAL_ILP0")) : 1, getenv("SHK_GAL_ILP1") ? atoi(getenv("SHK_GAL_ILP1")) : 4};
-    static const int grid_env[2] = {getenv("SHK_GAL_GRID0") ? atoi(getenv("SHK_GAL_GRID0")) : 1024, getenv("SHK_GAL_GRID1") ? atoi(getenv("SHK_GAL_GRID1")) : 2048};
-    static const int contig_env[2] = {getenv("SHK_GAL_CONTIG0") ? atoi(getenv("SHK_GAL_CONTIG0")) : 1, getenv("SHK_GAL_CONTIG1") ? atoi(getenv("SHK_GAL_CONTIG1")) : 0};
-    const int contig = contig_env[kind];
-    const int ilp = ilp_env[kind];
-    const int g = (int)std::min<int64_t>(grid_env[kind], std::max<int64_t>(1, (nslots + (int64_t)ilp * kBlock - 1) / ((int64_t)ilp * kBlock)));
+    const Tunables& T = tunables();
+    const int contig = T.gal_contig[kind];
+    const int ilp = T.gal_ilp[kind];
+    const int g = (int)std::min<int64_t>(T.gal_grid[kind], std::max<int64_t>(1, (nslots + (int64_t)ilp * kBlock - 1) / ((int64_t)ilp * kBlock)));
     if (ilp == 4) hipLaunchKernelGGL((k_galerkin<TC, 4>), dim3(g), dim3(kBlock), 0, c->stream, nslots, gptr, glist, fine, coarse, contig);
     else if (ilp == 2) hipLaunchKernelGGL((k_galerkin<TC, 2>), dim3(g), dim3(kBlock), 0, c->stream, nslots, gptr, glist, fine, coarse, contig);
     else hipLaunchKernelGGL((k_galerkin<TC, 1>), dim3(g), dim3(kBlock), 0, c->stream, nslots, gptr, glist, fine, coarse, contig);
@@ -295,8 +293,7 @@ __global__ __launch_bounds__(kBlock) void k_bgj_update(int n, int k0, int b, dou
 }
 // scratch: >= (2 n + kGjB) * kGjB doubles
 static void dense_invert_big(Ctx* c, int n, const double* A, double* inv, double* scratch) {
-    const bool pivotwise = getenv("SHK_GJ_PIVOTWISE") && atoi(getenv("SHK_GJ_PIVOTWISE")) != 0;   // cross-check switch
-    if (pivotwise) { dense_invert_pivotwise(c, n, A, inv, scratch); return; }
+    if (tunables().gj_pivotwise)   // cross-check switch { dense_invert_pivotwise(c, n, A, inv, scratch); return; }
     (void)hipMemcpyAsync(inv, A, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
     double *Cp = scratch, *Rp = scratch + (size_t)n * kGjB, *Dinv = Rp + (size_t)n * kGjB;
     const int gv = (n + kBlock - 1) / kBlock, gt = (n + 63) / 64;
@@ -703,7 +700,7 @@ static hipError_t lanczos_lambda(Ctx* c, const DevSell& A, const float* vals, co
     auto host_sum = [&](int cnt, double* sum) -> hipError_t {
         hipError_t e2 = hipMemcpyAsync(h.data(), part, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, c->stream);
         if (e2 != hipSuccess) return e2;
-        if ((e2 = hipStreamSynchronize(c->stream)) != hipSuccess) return e2;
+        if ((e2 = wait_stream(c)) != hipSuccess) return e2;
         double a = 0.0;
         for (int i = 0; i < cnt; ++i) a += h[i];
         *sum = a;
@@ -752,7 +749,7 @@ static hipError_t estimate_lambda(Ctx* c, AmgHierarchy& H) {
     // 2.37 / 2.54 at 10M rows where 16 give 2.07 -- but a mesh-independent measure (2.04 .. 2.07 from 12k to 10M rows)
     // that the dampings H.c1, H.c2, H.c4 were tuned against.
     constexpr int steps = 16;
-    static const int kLanczosSteps = getenv("SHK_AMG_LANCZOS") ? atoi(getenv("SHK_AMG_LANCZOS")) : 32;
+    const int kLanczosSteps = tunables().amg_lanczos;
     double lam = 0.0, gersh = 0.0, lanczos = 0.0;
     std::vector<double> h(2 * (size_t)kMaxParts);
     // Gershgorin bound G >= lambda_max(D^-1 A) over every sparse level: the dampings are capped so that no sweep
@@ -766,7 +763,7 @@ static hipError_t estimate_lambda(Ctx* c, AmgHierarchy& H) {
         hipError_t e = hipMemcpyAsync(h.data(), c->d_part + (size_t)P_AUX * kMaxParts, (size_t)grid * sizeof(double),
                                       hipMemcpyDeviceToHost, c->stream);
         if (e != hipSuccess) return e;
-        if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return e;
+        if ((e = wait_stream(c)) != hipSuccess) return e;
         for (int b = 0; b < grid; ++b) if (std::isfinite(h[b])) gersh = std::max(gersh, h[b]);
         if ((e = hipMemsetAsync(c->d_part + (size_t)P_AUX * kMaxParts, 0, (size_t)grid * sizeof(double), c->stream)) != hipSuccess)
             return e;
@@ -797,7 +794,7 @@ static hipError_t estimate_lambda(Ctx* c, AmgHierarchy& H) {
         }
         if ((e = hipMemcpyAsync(h.data(), c->d_part + (size_t)P_AUX * kMaxParts, 2 * (size_t)kMaxParts * sizeof(double),
                                 hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return e;
-        if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return e;
+        if ((e = wait_stream(c)) != hipSuccess) return e;
         double so = 0.0, sx = 0.0;
         for (int b = 0; b < grid; ++b) { so += h[b]; sx += h[kMaxParts + b]; }
         if (sx > 0.0 && std::isfinite(so)) lam = std::max(lam, std::sqrt(so / sx));
@@ -827,7 +824,7 @@ static hipError_t estimate_lambda(Ctx* c, AmgHierarchy& H) {
         if (e != hipSuccess) return e;
         if ((e = allreduce_buffer(c, d, d, (size_t)3 * R)) != hipSuccess) return e;
         if ((e = hipMemcpyAsync(buf.data(), d, 3 * R * sizeof(double), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return e;
-        if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return e;
+        if ((e = wait_stream(c)) != hipSuccess) return e;
         for (int r = 0; r < R; ++r) {
             lam = std::max(lam, buf[r]);
             gersh = std::max(gersh, buf[R + r]);
@@ -840,7 +837,7 @@ static hipError_t estimate_lambda(Ctx* c, AmgHierarchy& H) {
     // spectral bound the caps use: the Lanczos value + 5 % (it converges from below), never above Gershgorin's
     H.lam_max = lanczos > 0.0 ? std::min(gersh > 0.0 ? gersh : 1e300, 1.05 * lanczos) : gersh;
     damping_caps(H);
-    if (getenv("SHK_DEBUG"))
+    if (tunables().debug)
         fprintf(stderr, "[shk] multigrid smoother: 16-step power estimate %.4f, Lanczos(%d) %.4f, Gershgorin bound %.4f, "
                         "damping caps %.3f (2 sweeps) %.3f (4 sweeps)\n", lam, kLanczosSteps, lanczos, gersh, H.cap2, H.cap4);
     return hipSuccess;
@@ -860,7 +857,7 @@ hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense, bool d
     // top_only: a later Newton iteration whose iterate has barely moved (shk_newton_solve decides) keeps the coarse
     // operators and A*P of the step's first system and renews only the finest level's float copy: the cycle stays a
     // fixed linear operator, marginally staler (10M rows: +4..9 Krylov iterations in 550, -1.4 ms per step).
-    static const bool reuse = !(getenv("SHK_AMG_REUSE") && atoi(getenv("SHK_AMG_REUSE")) == 0);
+    const bool reuse = tunables().amg_reuse;
     if (top_only && reuse && primary && !refresh_dense && !decided && H.lambda != 0.0) {
         PhaseTimer t(c, SHK_PH_OTHER);
         hipLaunchKernelGGL(k_narrow, dim3(c->grid), dim3(kBlock), 0, c->stream, c->slots, c->d_vals, c->d_vals32);
@@ -940,7 +937,7 @@ hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense, bool d
     // depends on the mesh and on the anisotropy of the coefficients, not on their size.  They are renewed with every
     // lambda_period-th refresh of the dense inverse (4: every 32nd step), at once when the iteration feedback reports
     // a degraded preconditioner, and with every refresh on hierarchies too small to be worth the bookkeeping.
-    static const int lambda_period = getenv("SHK_AMG_LAMBDA_PERIOD") ? std::max(1, atoi(getenv("SHK_AMG_LAMBDA_PERIOD"))) : 4;
+    const int lambda_period = tunables().amg_lambda_period;
     const bool small = H.topA.n_rows < 200000;
     if (H.lambda == 0.0 || (refresh_dense && (small || ++H.lambda_age >= lambda_period))) {
         H.lambda_age = 0;
@@ -980,7 +977,7 @@ __global__ __launch_bounds__(kBlock) void k_amg_restrict4(int32_t n, const doubl
 
 // Tables of the four-level restriction for the active hierarchy (nlev = 0: unavailable).
 static RestrictArgs amg_restrict_args(const AmgHierarchy& H) {
-    static const bool enabled = !(getenv("SHK_FUSED_RESTRICT") && atoi(getenv("SHK_FUSED_RESTRICT")) == 0);
+    const bool enabled = tunables().fused_restrict;
     RestrictArgs ra{};
     if (!enabled || H.topA.n_rows > (1 << 21)) return ra;
     const size_t lt = tail_start(H);
@@ -998,10 +995,10 @@ static RestrictArgs amg_restrict_args(const AmgHierarchy& H) {
 
 template <bool FINE, class TX, class TR, class TO>
 static void launch_post(Ctx* c, const DevSell& A, const float* vals, const float* dinv, const TR* r, const TX* x, TO* xo,
-                        float w, const int* done) {
+                        float w, const int* done, int phase = SHK_PH_AMG_FINE) {
     AmgSmoothArgs<TX, TR, TO> a{A, vals, dinv, r, x, xo, w, done};
     const dim3 g(std::min((A.nslice + 3) / 4, 2048));
-    if (FINE) launch_phase(c, SHK_PH_AMG_FINE, k_amg_post<FINE, TX, TR, TO>, g, dim3(kBlock), 0, a);
+    if (FINE) launch_phase(c, phase, k_amg_post<FINE, TX, TR, TO>, g, dim3(kBlock), 0, a);
     else hipLaunchKernelGGL((k_amg_post<FINE, TX, TR, TO>), g, dim3(kBlock), 0, c->stream, a);
 }
 
@@ -1030,13 +1027,18 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
     const int32_t n_top = H.topA.n_rows, ncol_top = H.topA.n_cols;
     const size_t nx = H.xf.size();  // levels 0..nx-1 are sparse, level nx is the dense coarsest
     const int* done = &c->d_state->done;
-    static const double fw1 = getenv("SHK_AMG_W1") ? atof(getenv("SHK_AMG_W1")) : 0.0;   // experiment overrides
-    static const double fw2 = getenv("SHK_AMG_W2") ? atof(getenv("SHK_AMG_W2")) : 0.0;
+    const double fw1 = tunables().amg_w1, fw2 = tunables().amg_w2;   // experiment overrides
     const float w1 = (float)(fw1 > 0.0 ? fw1 : H.cap2 * H.c1 / H.lambda), w2 = (float)(fw2 > 0.0 ? fw2 : H.cap2 * H.c2 / H.lambda);
     const double l4 = H.lambda / H.cap4;   // the four-sweep sequences divide their c4[k] by this
     const float alpha = (float)H.alpha;
     hipError_t e;
     const size_t lt = H.rep ? nx : tail_start(H);   // a replicated coarse part takes over after the last launch level
+    // accounting: every launch of a replicated hierarchy is SHK_PH_AMG_REP (the part of a cycle that does not shrink
+    // with the number of GPUs); a context's own hierarchy splits into finest level, restrictions, dense solve and one
+    // slot per coarse level
+    const bool is_rep = H.top_four;
+    auto ph = [&](int p) { return is_rep ? (int)SHK_PH_AMG_REP : p; };
+    auto ph_level = [&](size_t l) { return is_rep ? (int)SHK_PH_AMG_REP : (int)SHK_PH_AMG_L1 + (int)std::min<size_t>(l, 8) - 1; };
     if (ncol_top > n_top && !(H.distributed && H.halo_levels > 0)) {
         // block-local smoothing on the finest level: the output vector's ghost entries (left over from the Krylov
         // loop's own exchange) must read as zero, or the preconditioner would change from call to call
@@ -1044,7 +1046,7 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
             return e;
     }
     {
-        PhaseTimer t(c, SHK_PH_AMG_COARSE);
+        PhaseTimer t(c, ph(SHK_PH_AMG_RESTRICT));
         const RestrictArgs ra = amg_restrict_args(H);
         // one launch for four levels while a workgroup has few groups to walk through (each costs a memory round
         // trip and four barriers); measured at 1M rows: 46.9 -> 45.4 ms/step, at 10M rows the plain cascade wins
@@ -1097,20 +1099,28 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
                                    H.cr, H.cglob, done);
             }
             if ((e = allreduce_buffer(c, H.cglob, H.cglob, (size_t)H.n_glob)) != hipSuccess) return e;
-            PhaseTimer t(c, SHK_PH_AMG_COARSE);
+            PhaseTimer t(c, SHK_PH_AMG_DENSE);
             if (!ta.dense_in_tail)
                 hipLaunchKernelGGL(k_dense_gemv<double>, dim3(gemv_grid), dim3(kBlock), 0, c->stream, ta.n_c, ta.row0,
                                    ta.ncols, ta.inv, (const double*)H.cglob, ta.cx, done);
             if (ta.nlev > 0 || ta.dense_in_tail) hipLaunchKernelGGL(k_amg_tail<2>, dim3(1), dim3(kTailThreads), 0, c->stream, ta);
         } else if (ta.dense_in_tail) {
-            PhaseTimer t(c, SHK_PH_AMG_COARSE);
+            PhaseTimer t(c, ph(SHK_PH_AMG_COARSE));
             hipLaunchKernelGGL(k_amg_tail<0>, dim3(1), dim3(kTailThreads), 0, c->stream, ta);
         } else {
-            PhaseTimer t(c, SHK_PH_AMG_COARSE);
-            if (ta.nlev > 0) hipLaunchKernelGGL(k_amg_tail<1>, dim3(1), dim3(kTailThreads), 0, c->stream, ta);
-            hipLaunchKernelGGL(k_dense_gemv<float>, dim3(gemv_grid), dim3(kBlock), 0, c->stream, ta.n_c, ta.row0, ta.ncols,
-                               ta.inv, (const float*)H.cr, ta.cx, done);
-            if (ta.nlev > 0) hipLaunchKernelGGL(k_amg_tail<2>, dim3(1), dim3(kTailThreads), 0, c->stream, ta);
+            if (ta.nlev > 0) {
+                PhaseTimer t(c, ph(SHK_PH_AMG_COARSE));
+                hipLaunchKernelGGL(k_amg_tail<1>, dim3(1), dim3(kTailThreads), 0, c->stream, ta);
+            }
+            {
+                PhaseTimer t(c, ph(SHK_PH_AMG_DENSE));
+                hipLaunchKernelGGL(k_dense_gemv<float>, dim3(gemv_grid), dim3(kBlock), 0, c->stream, ta.n_c, ta.row0, ta.ncols,
+                                   ta.inv, (const float*)H.cr, ta.cx, done);
+            }
+            if (ta.nlev > 0) {
+                PhaseTimer t(c, ph(SHK_PH_AMG_COARSE));
+                hipLaunchKernelGGL(k_amg_tail<2>, dim3(1), dim3(kTailThreads), 0, c->stream, ta);
+            }
         }
         return hipSuccess;
     };
@@ -1142,25 +1152,25 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
                 AmgFirstArgs<double> f{DevSell{X.n_fine, X.n_coarse_cols, X.ap_nslice, sell_fits_cache(X.ap_slots, kAmgSlotBytes),
                                                X.ap_ptr, X.ap_col, X.ap_rowlen, X.ap_cbase, X.ap_ptr16, X.ap_col16},
                                        X.ap_vals, H.top_dinv, rin, e_cols, X.agg, agg_off, H.x0, omega, alpha, done};
-                launch_phase(c, SHK_PH_AMG_FIRST, k_amg_first<true, double>, g, dim3(kBlock), 0, f);
+                launch_phase(c, ph(SHK_PH_AMG_FIRST), k_amg_first<true, double>, g, dim3(kBlock), 0, f);
             } else {
                 {
-                    PhaseTimer t(c, SHK_PH_AMG_COARSE);
+                    PhaseTimer t(c, ph(SHK_PH_AMG_COARSE));
                     hipLaunchKernelGGL(k_amg_prolong<float>, dim3(small_grid(X.n_fine)), dim3(kBlock), 0, c->stream,
                                        X.n_fine, alpha, X.agg, ec, zout, done);
                 }
                 if (halo && (e = halo_exchange_plan_f32(c, *HP, zout)) != hipSuccess) return e;
-                launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)zout, H.x0, omega, done);
+                launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)zout, H.x0, omega, done, ph(SHK_PH_AMG_FINE));
             }
             if (halo && c->overlap && H.plan_of[0] == 0 && A.ptr == c->d_sell_ptr) {
                 if ((e = launch_post_split(c, A, H.top_vals, H.top_dinv, rin, H.x0, zout, w2, done)) != hipSuccess) return e;
             } else {
                 if (halo && (e = halo_exchange_plan_f32(c, *HP, H.x0)) != hipSuccess) return e;
-                launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)H.x0, zout, w2, done);
+                launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)H.x0, zout, w2, done, ph(SHK_PH_AMG_FINE));
             }
             if (four) {
-                launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)zout, H.x0, (float)(H.c4[2] / l4), done);
-                launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)H.x0, zout, (float)(H.c4[3] / l4), done);
+                launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)zout, H.x0, (float)(H.c4[2] / l4), done, ph(SHK_PH_AMG_FINE));
+                launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)H.x0, zout, (float)(H.c4[3] / l4), done, ph(SHK_PH_AMG_FINE));
             }
         } else {
             const AmgLevel& L = H.lv[l];
@@ -1176,18 +1186,18 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
                 AmgFirstArgs<float> f{DevSell{X.n_fine, X.n_coarse_cols, X.ap_nslice, sell_fits_cache(X.ap_slots, kAmgSlotBytes),
                                               X.ap_ptr, X.ap_col, X.ap_rowlen, X.ap_cbase, X.ap_ptr16, X.ap_col16},
                                       X.ap_vals, L.dinv, L.r, e_cols, X.agg, agg_off, L.x, lw1, alpha, done};
-                PhaseTimer t(c, SHK_PH_AMG_COARSE);
+                PhaseTimer t(c, ph_level(l));
                 hipLaunchKernelGGL((k_amg_first<false, float>), g, dim3(kBlock), 0, c->stream, f);
             } else {
                 {
-                    PhaseTimer t(c, SHK_PH_AMG_COARSE);
+                    PhaseTimer t(c, ph_level(l));
                     hipLaunchKernelGGL(k_amg_prolong<float>, dim3(small_grid(X.n_fine)), dim3(kBlock), 0, c->stream,
                                        X.n_fine, alpha, X.agg, ec, L.x2, done);
                 }
                 // distributed smoothing: the sweep needs the neighbours' current iterate on the ghost columns
                 // (without the exchange the ghost entries stay zero = block-local smoothing on that level)
                 if (halo && (e = halo_exchange_plan_f32(c, *HP, L.x2)) != hipSuccess) return e;
-                PhaseTimer t(c, SHK_PH_AMG_COARSE);
+                PhaseTimer t(c, ph_level(l));
                 launch_post<false>(c, A, L.vals, L.dinv, (const float*)L.r, (const float*)L.x2, L.x, lw1, done);
             }
             if (halo && (e = halo_exchange_plan_f32(c, *HP, L.x)) != hipSuccess) return e;
@@ -1200,7 +1210,7 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
                                                   hipMemcpyDeviceToDevice, c->stream)) != hipSuccess)
                     return e;
             }
-            PhaseTimer t(c, SHK_PH_AMG_COARSE);
+            PhaseTimer t(c, ph_level(l));
             launch_post<false>(c, A, L.vals, L.dinv, (const float*)L.r, (const float*)L.x, L.x2, lw2, done);
             if (more) {
                 launch_post<false>(c, A, L.vals, L.dinv, (const float*)L.r, (const float*)L.x2, L.x, (float)(H.c4[2] / l4), done);
@@ -1254,7 +1264,7 @@ static hipError_t exchange_ids(Ctx* c, const HaloPlan& P, int64_t n_ghost, const
     if ((e = halo_exchange_plan(c, P, c->d_io)) != hipSuccess) return e;
     if ((e = hipMemcpyAsync(buf.data(), c->d_io, buf.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
         return e;
-    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return e;
+    if ((e = wait_stream(c)) != hipSuccess) return e;
     ghost.resize((size_t)n_ghost);
     for (int64_t g = 0; g < n_ghost; ++g) ghost[g] = (int32_t)buf[P.n_own + g];
     return hipSuccess;
@@ -1269,7 +1279,7 @@ static hipError_t allgather_int(Ctx* c, int32_t mine, std::vector<int32_t>& all)
     if (e != hipSuccess) return e;
     if ((e = allreduce_buffer(c, d, d, (size_t)R)) != hipSuccess) return e;
     if ((e = hipMemcpyAsync(buf.data(), d, R * sizeof(double), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return e;
-    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return e;
+    if ((e = wait_stream(c)) != hipSuccess) return e;
     all.resize(R);
     for (int r = 0; r < R; ++r) all[r] = (int32_t)buf[r];
     return hipSuccess;
@@ -1287,7 +1297,7 @@ static hipError_t allgather_i32(Ctx* c, const std::vector<int32_t>& mine, int64_
     e = hipMemcpyAsync(d, buf.data(), buf.size() * sizeof(double), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = allreduce_buffer(c, d, d, buf.size());
     if (e == hipSuccess) e = hipMemcpyAsync(buf.data(), d, buf.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = wait_stream(c);
     (void)hipFree(d);
     if (e != hipSuccess) return e;
     all.resize((size_t)total);
@@ -1307,13 +1317,13 @@ int amg_setup_distributed(Ctx* c, std::string& err) {
     if ((size_t)2 * c->n_loc < (size_t)R) { err = "too many ranks for the staging buffer"; return -1; }
     AmgHierarchy& H = c->amg_dist;
     H.distributed = true;
-    if (const char* s = getenv("SHK_AMG_HALO_LEVELS")) H.halo_levels = std::max(0, atoi(s));
+    if (tunables().amg_halo_levels >= 0) H.halo_levels = tunables().amg_halo_levels;
     // first level gathered and replicated on every subdomain: the first whose global size is at most this (0: never)
     // (default 200 000: level 3 of a 10M-row mesh, level 2 at 1M rows; the gathered right-hand side is then at most
     // 1.6 MB per cycle.  Rehearsed with 4 | 5 subdomains at 10M rows: 48 | 56 iterations per Newton iteration, the same
     // as with every level exchanging ghosts, against 76 | 86 with two exchanging levels and block-local ones below.)
     int64_t rep_rows = 200000;
-    if (const char* s = getenv("SHK_AMG_REP_ROWS")) rep_rows = std::max(0, atoi(s));
+    if (tunables().amg_rep_rows >= 0) rep_rows = tunables().amg_rep_rows;
     SellPattern G;                       // the replicated global level, if any
     std::vector<int32_t> G_diag;
     std::vector<AmgLevelPlan> plans;
@@ -1432,7 +1442,7 @@ int amg_setup_distributed(Ctx* c, std::string& err) {
             if ((e = hipMalloc(&q, CP.h_send_idx.size() * sizeof(int32_t))) != hipSuccess) { err = hipGetErrorString(e); return -1; }
             c->allocs.push_back(q);
             CP.d_send_idx = reinterpret_cast<int32_t*>(q);
-            if ((e = hipMemcpy(q, CP.h_send_idx.data(), CP.h_send_idx.size() * sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess) {
+            if ((e = upload_sync(c, q, CP.h_send_idx.data(), CP.h_send_idx.size() * sizeof(int32_t))) != hipSuccess) {
                 err = hipGetErrorString(e); return -1;
             }
         }
@@ -1451,7 +1461,7 @@ int amg_setup_distributed(Ctx* c, std::string& err) {
         std::vector<int32_t> ident((size_t)G.n_rows);
         for (int32_t i = 0; i < G.n_rows; ++i) ident[i] = i;
         PlanOptions opt;
-        if (const char* s = getenv("SHK_AMG_COARSEST")) opt.amg_coarsest = atoi(s);
+        opt.amg_coarsest = tunables().amg_coarsest;
         opt.amg_cost_nnz = (double)c->nnz * R;   // the dense level is sized against the whole fine operator
         std::vector<AmgLevelPlan> rplans;
         std::string perr = build_amg_levels(G, ident, opt, rplans);
@@ -1461,8 +1471,7 @@ int amg_setup_distributed(Ctx* c, std::string& err) {
         if ((e = amg_upload_rep_top(c, *H.rep, G, G_diag)) != hipSuccess ||
             (e = amg_upload(c, rplans, *H.rep, G.n_rows, &ident)) != hipSuccess) { err = hipGetErrorString(e); return -1; }
     }
-    // (amg_upload zero-fills on the null stream; the cycles run on the context's non-blocking stream)
-    if (hipDeviceSynchronize() != hipSuccess) { err = "synchronize"; return -1; }
+    if (wait_stream(c) != hipSuccess) { err = "synchronize"; return -1; }
     return 0;
 }
 

@@ -35,6 +35,44 @@ int set_error(const std::string& msg) { return fail(msg); }
 #define CHECK_CTX(c) \
     if (!(c)) return fail("null context")
 
+// Waiting on the device while RCCL collectives are in flight must not be able to hang forever: a peer that died or a
+// mismatched collective would otherwise block every rank inside hipEventSynchronize / hipStreamSynchronize with no
+// message.  With an RCCL communicator of > 1 ranks the host polls with a deadline (SHK_COMM_TIMEOUT_S, default 300 s)
+// and turns a stall into an error; the context is then POISONED: its stream will never drain, so shk_destroy skips
+// every call that would wait for it.  Single-GPU contexts block as usual.
+static const char* kStallMsg = "the device stream stalled: no progress for SHK_COMM_TIMEOUT_S seconds with RCCL collectives in "
+                               "flight (a peer rank died, or the ranks diverged); the context is poisoned -- exit the process";
+static hipError_t wait_event(Ctx* c, hipEvent_t ev) {
+    if (c->poisoned) return hipErrorLaunchTimeOut;
+    if (c->comm.kind != Comm::RCCL || c->comm.nranks <= 1) return hipEventSynchronize(ev);
+    const double limit = tunables().comm_timeout_s;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+            c->poisoned = true;
+            return hipErrorLaunchTimeOut;
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+}
+namespace shk {
+hipError_t wait_stream(Ctx* c) {
+    if (c->poisoned) return hipErrorLaunchTimeOut;
+    if (c->comm.kind != Comm::RCCL || c->comm.nranks <= 1) return hipStreamSynchronize(c->stream);
+    hipError_t e = hipEventRecord(c->poll_ev[2], c->stream);
+    return e != hipSuccess ? e : wait_event(c, c->poll_ev[2]);
+}
+}
+// every host wait of the API goes through the deadline
+#define WAITCHK(c)                                                                       \
+    do {                                                                                 \
+        hipError_t w_ = wait_stream(c);                                                  \
+        if (w_ == hipErrorLaunchTimeOut) return fail(kStallMsg);                         \
+        if (w_ != hipSuccess) return fail(std::string("stream wait failed: ") + hipGetErrorString(w_)); \
+    } while (0)
+
 template <class T>
 static hipError_t dev_alloc(Ctx* c, T** p, size_t n) {
     void* q = nullptr;
@@ -52,7 +90,7 @@ static hipError_t upload(Ctx* c, T** p, const std::vector<T>& h) {
     hipError_t e = dev_alloc(c, p, h.size());
     if (e != hipSuccess) return e;
     if (h.empty()) return hipSuccess;
-    return hipMemcpy(*p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    return upload_sync(c, *p, h.data(), h.size() * sizeof(T));
 }
 
 static void derive_params(Ctx* c) {
@@ -117,7 +155,7 @@ hipError_t amg_upload_rep_top(Ctx* c, AmgHierarchy& R, const SellPattern& G, con
     R.t_slots = G.slots;
     if ((e = dev_alloc(c, &R.t_vals, (size_t)G.slots)) != hipSuccess) return e;
     if ((e = dev_alloc(c, &R.t_dinv, (size_t)G.nslice * kSlice)) != hipSuccess) return e;
-    if ((e = hipMemset(R.t_dinv, 0, (size_t)G.nslice * kSlice * sizeof(float))) != hipSuccess) return e;
+    if ((e = zero_async(c, R.t_dinv, (size_t)G.nslice * kSlice * sizeof(float))) != hipSuccess) return e;
     R.topA = DevSell{G.n_rows, G.n_cols, G.nslice, sell_fits_cache(G.slots, kAmgSlotBytes), R.t_ptr, R.t_col, R.t_rowlen,
                      R.t_cbase, R.t_ptr16, R.t_col16};
     R.top_vals = R.t_vals;
@@ -208,7 +246,7 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
             float** vs[] = {&L.dinv, &L.x, &L.x2, &L.x3, &L.r};
             for (float** v : vs) {
                 if ((e = dev_alloc(c, v, nr)) != hipSuccess) return e;
-                if ((e = hipMemset(*v, 0, nr * sizeof(float))) != hipSuccess) return e;
+                if ((e = zero_async(c, *v, nr * sizeof(float))) != hipSuccess) return e;
             }
         } else {
             const size_t rows = H.distributed ? (size_t)H.n_glob : (size_t)LP.n_coarse;
@@ -223,27 +261,28 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
         }
         LP = AmgLevelPlan();  // host copy no longer needed
     }
-    if (const char* sa = getenv("SHK_AMG_ALPHA")) H.alpha = atof(sa);
-    if (const char* sa = getenv("SHK_AMG_COARSE4")) H.coarse4 = atoi(sa) != 0;
-    if (const char* sa = getenv("SHK_AMG_COARSE4_FROM")) H.coarse4_from = std::max(1, atoi(sa));
-    if (const char* sa = getenv("SHK_AMG_DENSE_PERIOD")) H.dense_period = std::max(1, atoi(sa));
+    const Tunables& T = tunables();
+    if (T.amg_alpha > 0.0) H.alpha = T.amg_alpha;
+    if (T.amg_coarse4 >= 0) H.coarse4 = T.amg_coarse4 != 0;
+    if (T.amg_coarse4_from > 0) H.coarse4_from = T.amg_coarse4_from;
+    if (T.amg_dense_period > 0) H.dense_period = T.amg_dense_period;
     {   // cycle doubling at the first sparse level of at most SHK_AMG_W_ROWS rows (experiment; default 0 = V-cycle:
         // measured at 10M | 1M rows it saves 4 | 10 % of the iterations and costs 5 | 44 % more time per step)
-        const int64_t wrows = getenv("SHK_AMG_W_ROWS") ? atoll(getenv("SHK_AMG_W_ROWS")) : 0;
+        const int64_t wrows = T.amg_w_rows;
         H.w_level = 0;
         for (size_t l = 1; l < nx && wrows > 0; ++l)
             if (H.lv[l].n > 0 && H.lv[l].n <= wrows) { H.w_level = l; break; }
     }
-    if (const char* sa = getenv("SHK_AMG_DAMP_SCALE")) {   // robustness experiments: every damping of the cycle times f
-        const double f = atof(sa);
-        if (f > 0.0) { H.c1 *= f; H.c2 *= f; for (double& v : H.c4) v *= f; }
+    if (T.amg_damp_scale > 0.0) {   // robustness experiments: every damping of the cycle times f
+        const double f = T.amg_damp_scale;
+        H.c1 *= f; H.c2 *= f; for (double& v : H.c4) v *= f;
     }
     if ((e = dev_alloc(c, &H.x0, (size_t)n_loc0)) != hipSuccess) return e;
     if ((e = dev_alloc(c, &H.x1, (size_t)n_loc0)) != hipSuccess) return e;
     if ((e = dev_alloc(c, &H.x2, (size_t)n_loc0)) != hipSuccess) return e;
-    if ((e = hipMemset(H.x2, 0, (size_t)n_loc0 * sizeof(float))) != hipSuccess) return e;
-    if ((e = hipMemset(H.x1, 0, (size_t)n_loc0 * sizeof(float))) != hipSuccess) return e;
-    return hipMemset(H.x0, 0, (size_t)n_loc0 * sizeof(float));
+    if ((e = zero_async(c, H.x2, (size_t)n_loc0 * sizeof(float))) != hipSuccess) return e;
+    if ((e = zero_async(c, H.x1, (size_t)n_loc0 * sizeof(float))) != hipSuccess) return e;
+    return zero_async(c, H.x0, (size_t)n_loc0 * sizeof(float));
 }
 }  // namespace shk
 
@@ -293,14 +332,16 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
         set_poly_rule(c);
     }
     PlanOptions opt;
-    if (const char* s = getenv("SHK_ASM_SLICES")) opt.slices_max = std::max(1, atoi(s));
-    if (const char* s = getenv("SHK_ASM_CELLS")) opt.cells_max = std::max(64, atoi(s));
-    opt.cells_max = std::min(opt.cells_max, kAsmCellsMax);
+    const Tunables& T = tunables();
+    // k_assemble finds a slot's slice with three compares: a block owns at most 4 slices
+    if (T.asm_slices < 1 || T.asm_slices > 4) { delete c; return fail("SHK_ASM_SLICES must be in 1..4 (the assembly kernel's limit)"); }
+    opt.slices_max = T.asm_slices;
+    opt.cells_max = std::min(std::max(64, T.asm_cells), kAsmCellsMax);
     opt.slots_max = kAsmSlotsMax;
-    if (const char* s = getenv("SHK_SORT_WINDOW")) opt.sort_window = std::max(64, atoi(s));
-    if (const char* s = getenv("SHK_REORDER")) opt.reorder = atoi(s) != 0;
-    if (const char* s = getenv("SHK_AMG")) opt.amg = atoi(s) != 0;
-    if (const char* s = getenv("SHK_AMG_COARSEST")) opt.amg_coarsest = atoi(s);
+    opt.sort_window = std::max(64, T.sort_window);
+    opt.reorder = T.reorder;
+    opt.amg = T.amg;
+    opt.amg_coarsest = T.amg_coarsest;
     std::string err = build_plan(c->n_own, c->n_loc, ne, xy, cells, opt, c->plan);
     if (!err.empty()) { delete c; return fail("plan: " + err); }
     const HostPlan& P = c->plan;
@@ -310,7 +351,7 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
     c->cells_staged = (int64_t)P.blk_cells.size();
     c->grid = (int)std::min<int64_t>(kMaxParts, std::max<int64_t>(1, (c->n_own + kBlock - 1) / kBlock));
     c->np = c->grid;
-    if (const char* w = getenv("SHK_WARM_ITS")) c->warm_its = std::max(1, std::min(atoi(w), (int)Ctx::kWarmIts));   // experiments
+    c->warm_its = std::max(1, std::min(T.warm_its, (int)Ctx::kWarmIts));   // experiments
     if (P.verts_max > kAsmVertsMax) { delete c; return fail("an assembly block touches more than 768 vertices (degenerate mesh?)"); }
     c->asm_lds = assemble_lds_bytes(P, &c->asm_region_a);
     if (c->asm_lds > 160 * 1024) { delete c; return fail("assembly LDS budget exceeds 160 KiB"); }
@@ -327,7 +368,7 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
     if ((e = hipEventCreateWithFlags(&c->poll_ev[2], hipEventDisableTiming)) != hipSuccess) return bail(e, "event");
     // mesh (internal numbering)
     if ((e = dev_alloc(c, &c->d_xy, nl)) != hipSuccess) return bail(e, "alloc xy");
-    if ((e = hipMemcpy(c->d_xy, P.xy.data(), nl * sizeof(double2), hipMemcpyHostToDevice)) != hipSuccess)
+    if ((e = upload_sync(c, c->d_xy, P.xy.data(), nl * sizeof(double2))) != hipSuccess)
         return bail(e, "copy xy");
 #define UP(dst, src) if ((e = upload(c, &c->dst, P.src)) != hipSuccess) return bail(e, "upload " #src)
     UP(d_cells, cells); UP(d_perm, perm); UP(d_sell_ptr, A.ptr); UP(d_sell_col, A.col); UP(d_rowlen, A.rowlen);
@@ -349,26 +390,26 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
     for (int fidx = 0; fidx < SHK_FIELD_COUNT; ++fidx) {
         if (fidx == SHK_Q) continue;
         if ((e = dev_alloc(c, &c->f[fidx], nl)) != hipSuccess) return bail(e, "alloc field");
-        if ((e = hipMemset(c->f[fidx], 0, nl * sizeof(double))) != hipSuccess) return bail(e, "memset");
+        if ((e = zero_async(c, c->f[fidx], nl * sizeof(double))) != hipSuccess) return bail(e, "memset");
     }
     double** vecs[] = {&c->d_melt_tmp, &c->d_b_tmp, &c->d_m0, &c->d_F, &c->d_dinv, &c->d_r, &c->d_rhat,
                        &c->d_p, &c->d_v, &c->d_s, &c->d_t, &c->d_y, &c->d_ytot, &c->d_rhs};
     for (double** v : vecs) {
         if ((e = dev_alloc(c, v, nl)) != hipSuccess) return bail(e, "alloc vector");
-        if ((e = hipMemset(*v, 0, nl * sizeof(double))) != hipSuccess) return bail(e, "memset");
+        if ((e = zero_async(c, *v, nl * sizeof(double))) != hipSuccess) return bail(e, "memset");
     }
     if ((e = dev_alloc(c, &c->d_vals, (size_t)c->slots)) != hipSuccess) return bail(e, "alloc vals");
     if ((e = dev_alloc(c, &c->d_vals_s, (size_t)c->slots)) != hipSuccess) return bail(e, "alloc vals_s");
     if ((e = dev_alloc(c, &c->d_vals32, (size_t)c->slots)) != hipSuccess) return bail(e, "alloc vals32");
     if ((e = dev_alloc(c, &c->d_dinv32, nl)) != hipSuccess) return bail(e, "alloc dinv32");
-    if ((e = hipMemset(c->d_dinv32, 0, nl * sizeof(float))) != hipSuccess) return bail(e, "memset");
+    if ((e = zero_async(c, c->d_dinv32, nl * sizeof(float))) != hipSuccess) return bail(e, "memset");
     if ((e = dev_alloc(c, &c->d_bcflag, nl)) != hipSuccess) return bail(e, "alloc bcflag");
-    if ((e = hipMemset(c->d_bcflag, 0, nl)) != hipSuccess) return bail(e, "memset");
+    if ((e = zero_async(c, c->d_bcflag, nl)) != hipSuccess) return bail(e, "memset");
     if ((e = dev_alloc(c, &c->d_part, (size_t)P_COUNT * kMaxParts)) != hipSuccess) return bail(e, "alloc partials");
-    if ((e = hipMemset(c->d_part, 0, P_COUNT * kMaxParts * sizeof(double))) != hipSuccess) return bail(e, "memset");
+    if ((e = zero_async(c, c->d_part, P_COUNT * kMaxParts * sizeof(double))) != hipSuccess) return bail(e, "memset");
     c->d_red = c->d_part;
     if ((e = dev_alloc(c, &c->d_state, 1)) != hipSuccess) return bail(e, "alloc state");
-    if ((e = hipMemset(c->d_state, 0, sizeof(KrylovState))) != hipSuccess) return bail(e, "memset");
+    if ((e = zero_async(c, c->d_state, sizeof(KrylovState))) != hipSuccess) return bail(e, "memset");
     if ((e = hipHostMalloc((void**)&c->h_state, 2 * sizeof(KrylovState))) != hipSuccess) return bail(e, "pinned");
     if ((e = hipHostMalloc((void**)&c->h_part, kMaxParts * sizeof(double))) != hipSuccess) return bail(e, "pinned");
     if ((e = prepare_kernels(c)) != hipSuccess) return bail(e, "hipFuncSetAttribute(dynamic LDS)");
@@ -381,11 +422,11 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
         float** vs[] = {&c->d_phat, &c->d_shat};
         for (float** v : vs) {
             if ((e = dev_alloc(c, v, nl)) != hipSuccess) return bail(e, "amg alloc");
-            if ((e = hipMemset(*v, 0, nl * sizeof(float))) != hipSuccess) return bail(e, "memset");
+            if ((e = zero_async(c, *v, nl * sizeof(float))) != hipSuccess) return bail(e, "memset");
         }
     }
-    // the zero fills above ran on the null stream, which the context's non-blocking stream is not ordered with
-    if ((e = hipDeviceSynchronize()) != hipSuccess) return bail(e, "synchronize");
+    // (every upload and zero fill above travelled on the context's own stream)
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(e, "synchronize");
     *out = reinterpret_cast<shk_ctx*>(c);
     return 0;
 }
@@ -398,6 +439,14 @@ int shk_destroy(shk_ctx* ctx) {
     if (!ctx) return 0;
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     (void)hipSetDevice(c->device);
+    if (c->poisoned) {
+        // The stream holds a collective that will never complete: hipStreamSynchronize, ncclCommDestroy, hipFree and
+        // hipStreamDestroy would all wait for it.  Abort the communicator if the library can, leave the device memory
+        // to the process exit, and return -- so that the rank can exit non-zero and the launcher tears the job down.
+        comm_abort(c);
+        delete c;
+        return 0;
+    }
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
     comm_destroy(c);
@@ -474,7 +523,7 @@ int shk_set_field(shk_ctx* ctx, int32_t field, const double* host) {
     HIPCHK(hipMemcpyAsync(c->d_io, host, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     if (field == SHK_Q) launch_split_q(c, c->d_io);
     else launch_permute_in(c, c->d_io, c->f[field]);
-    HIPCHK(hipStreamSynchronize(c->stream));
+    WAITCHK(c);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -482,7 +531,7 @@ int shk_set_field(shk_ctx* ctx, int32_t field, const double* host) {
 static int get_vector(Ctx* c, const double* dev, double* host) {
     launch_permute_out(c, dev, c->d_io);
     HIPCHK(hipMemcpyAsync(host, c->d_io, (size_t)c->n_loc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    WAITCHK(c);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -496,7 +545,7 @@ int shk_get_field(shk_ctx* ctx, int32_t field, double* host) {
     if (field == SHK_Q) {
         launch_join_q(c, c->d_io);
         HIPCHK(hipMemcpyAsync(host, c->d_io, (size_t)c->n_loc * 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        WAITCHK(c);
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -517,7 +566,7 @@ int shk_set_dirichlet(shk_ctx* ctx, int64_t n, const int32_t* dofs, double value
     // copy would be ordered with nothing); `flag` lives until the synchronisation below
     HIPCHK(hipMemcpyAsync(c->d_bcflag, flag.data(), (size_t)c->n_loc, hipMemcpyHostToDevice, c->stream));
     launch_slot_bc(c);   // per-slot Dirichlet codes into the plan words (all zero when n == 0)
-    HIPCHK(hipStreamSynchronize(c->stream));
+    WAITCHK(c);
     c->has_bc = n > 0;
     c->bc_value = value;
     c->assembled = false;
@@ -561,7 +610,7 @@ int shk_get_csr(shk_ctx* ctx, int32_t* rowptr, int32_t* colidx, double* values) 
         HIPCHK(hipSetDevice(c->device));
         sv.resize((size_t)c->slots);
         HIPCHK(hipMemcpyAsync(sv.data(), c->d_vals, sv.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        WAITCHK(c);
     }
     std::vector<int32_t> rp, ci;
     std::vector<double> va;
@@ -572,33 +621,12 @@ int shk_get_csr(shk_ctx* ctx, int32_t* rowptr, int32_t* colidx, double* values) 
     return 0;
 }
 
-// Waiting on the device while RCCL collectives are in flight must not be able to hang forever: a peer that died or a
-// mismatched collective would otherwise block every rank inside hipEventSynchronize / hipStreamSynchronize with no
-// message.  With an RCCL communicator of > 1 ranks the host polls with a deadline (SHK_COMM_TIMEOUT_S, default 300 s)
-// and turns a stall into an error; single-GPU contexts block as usual.
-static hipError_t wait_event(Ctx* c, hipEvent_t ev) {
-    if (c->comm.kind != Comm::RCCL || c->comm.nranks <= 1) return hipEventSynchronize(ev);
-    static const double limit = getenv("SHK_COMM_TIMEOUT_S") ? atof(getenv("SHK_COMM_TIMEOUT_S")) : 300.0;
-    const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-        const hipError_t e = hipEventQuery(ev);
-        if (e != hipErrorNotReady) return e;
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) return hipErrorLaunchTimeOut;
-        std::this_thread::sleep_for(std::chrono::microseconds(20));
-    }
-}
-static hipError_t wait_stream(Ctx* c) {
-    if (c->comm.kind != Comm::RCCL || c->comm.nranks <= 1) return hipStreamSynchronize(c->stream);
-    hipError_t e = hipEventRecord(c->poll_ev[2], c->stream);
-    return e != hipSuccess ? e : wait_event(c, c->poll_ev[2]);
-}
-
 // One BiCGStab run on A' y = rhs (x0 = 0).  The host only polls a stop flag: chunk k+1 is already queued
 // when chunk k's flag is read, so the GPU never idles; kernels after the stop return immediately.
 static int krylov_inner(Ctx* c, const double* rhs, int max_it, KrylovState* out) {
     krylov_init(c, rhs);
     // iterations enqueued per stop-flag poll: 0 = auto (a multigrid iteration is ~90 launches: poll often)
-    static const int env_chunk = getenv("SHK_KRYLOV_CHUNK") ? atoi(getenv("SHK_KRYLOV_CHUNK")) : 0;   // experiments
+    const int env_chunk = tunables().krylov_chunk;   // experiments
     const int chunk = c->params.krylov_check_every > 0 ? c->params.krylov_check_every
                       : env_chunk > 0 ? env_chunk : c->use_amg ? 2 : 16;
     int it = 0, slot = 0;
@@ -625,7 +653,7 @@ static int krylov_inner(Ctx* c, const double* rhs, int max_it, KrylovState* out)
     // with f = 10, 58.4 -> 57.5 ms per step, but the GPU idles during those round trips and every kernel launched after an
     // idle gap runs slower (k_spmv 165 -> 188 us on average over the step, the smoothers alike) -- the launches saved are
     // paid back in kernel time, and the per-kernel figures of the bench line stop describing the kernels.
-    static const double near2 = getenv("SHK_KRYLOV_NEAR") ? std::pow(atof(getenv("SHK_KRYLOV_NEAR")), 2) : 0.0;
+    const double near2 = std::pow(tunables().krylov_near, 2);
     bool careful = false;
     while (e == hipSuccess) {
         if (!careful) {
@@ -644,9 +672,7 @@ static int krylov_inner(Ctx* c, const double* rhs, int max_it, KrylovState* out)
         if (it > max_it + 4 * chunk) { rc = fail("Krylov driver ran past max_it without a stop flag"); break; }
     }
     c->params.krylov_max_it = saved_max;
-    if (e == hipErrorLaunchTimeOut)
-        return fail("the Krylov loop stalled: no progress on the stream for SHK_COMM_TIMEOUT_S seconds with RCCL collectives in "
-                    "flight (a peer rank died, or the ranks diverged)");
+    if (e == hipErrorLaunchTimeOut) return fail(kStallMsg);
     if (e != hipSuccess) return fail(std::string("krylov enqueue: ") + hipGetErrorString(e));
     return rc;
 }
@@ -654,7 +680,7 @@ static int krylov_inner(Ctx* c, const double* rhs, int max_it, KrylovState* out)
 static int read_aux_norm(Ctx* c, double* out) {  // fixed-order host sum of the (reduced) P_AUX partials
     HIPCHK(hipMemcpyAsync(c->h_part, c->d_red + (size_t)P_AUX * c->red_stride, (size_t)c->np * sizeof(double),
                           hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(wait_stream(c));
+    WAITCHK(c);
     double s = 0.0;
     for (int i = 0; i < c->np; ++i) s += c->h_part[i];
     *out = std::sqrt(s);
@@ -743,8 +769,12 @@ static int krylov_solve(Ctx* c, int* its, int* converged, double* relres, int ne
     }
     if (c->use_amg && first_of_step) {  // feedback for the coarsest-inverse refresh policy (like with like:
         int cost = total;               // only the first Newton system of each solve is compared)
-        if (warm && r_start > target && rhs_norm > target)   // a warm start covers fewer decades: scale to the full span
-            cost = (int)std::lround(total * std::log(rhs_norm / target) / std::log(r_start / target));
+        // a warm start covers fewer decades: scale to the full span -- only when the start is clearly above the target
+        // (a projected guess that already sits at the target would blow the ratio up), by at most 4x, within max_it
+        if (warm && r_start > 10.0 * target && rhs_norm > target) {
+            const double f = std::min(4.0, std::log(rhs_norm / target) / std::log(r_start / target));
+            cost = (int)std::min<double>(std::lround(total * f), (double)c->params.krylov_max_it);
+        }
         c->amg->its_last = cost;
         if (c->amg->its_fresh == 0) c->amg->its_fresh = cost;
     }
@@ -763,7 +793,7 @@ int shk_linear_solve(shk_ctx* ctx, int32_t* its, int32_t* converged, double* rel
     double rr = 0;
     if (krylov_solve(c, &k, &cv, &rr)) return -1;
     launch_newton_update(c, false);  // dx = D^-1 y without touching N
-    HIPCHK(hipStreamSynchronize(c->stream));
+    WAITCHK(c);
     if (its) *its = k;
     if (converged) *converged = cv;
     if (rel_residual) *rel_residual = rr;
@@ -892,8 +922,7 @@ int shk_set_halo(shk_ctx* ctx, int32_t n_nbr, const int32_t* nbr_rank, const int
     if (dev_alloc(c, &m.d_sendbuf, (size_t)nsend) != hipSuccess) return fail("halo alloc");
     if (dev_alloc(c, &m.d_recvbuf, (size_t)nrecv) != hipSuccess) return fail("halo alloc");
     if (nsend > 0)
-        HIPCHK(hipMemcpy(P.d_send_idx, P.h_send_idx.data(), (size_t)nsend * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIPCHK(hipDeviceSynchronize());   // null-stream upload, used from the context's (non-blocking) stream
+        HIPCHK(upload_sync(c, P.d_send_idx, P.h_send_idx.data(), (size_t)nsend * sizeof(int32_t)));
     HIPCHK(hipHostMalloc((void**)&m.h_send, std::max<size_t>(1, (size_t)nsend) * sizeof(double)));
     HIPCHK(hipHostMalloc((void**)&m.h_recv, std::max<size_t>(1, (size_t)nrecv) * sizeof(double)));
     m.h_red_cap = (size_t)P_COUNT * kMaxParts;
@@ -925,7 +954,7 @@ static hipError_t overlap_setup(Ctx* c) {
     if ((e = hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming)) != hipSuccess) return e;
     if ((e = hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming)) != hipSuccess) return e;
     c->overlap = true;
-    return hipDeviceSynchronize();   // the uploads above used the null stream, the sweeps use the context's
+    return hipStreamSynchronize(c->stream);   // (uploads and fills above are on the context's stream)
 }
 
 static int comm_common(Ctx* c, int rank, int nranks, bool overlap_default) {
@@ -946,7 +975,7 @@ static int comm_common(Ctx* c, int rank, int nranks, bool overlap_default) {
     // send / recv is expected to take, and RCCL has never run with several ranks in this build's environment: the first
     // multi-GPU runs should measure the plain path first.  (Host-staged transport, 2 subdomains sharing one GPU at 1M
     // rows: 133 -> 183 ms per step with it -- the callback blocks the host anyway.)
-    const bool want_overlap = getenv("SHK_OVERLAP") ? atoi(getenv("SHK_OVERLAP")) != 0 : overlap_default;
+    const bool want_overlap = tunables().overlap >= 0 ? tunables().overlap != 0 : overlap_default;
     if (nranks > 1 && want_overlap && !c->overlap) HIPCHK(overlap_setup(c));
     c->comm.rank = rank;
     c->comm.nranks = nranks;
@@ -994,6 +1023,32 @@ int shk_comm_selftest(shk_ctx* ctx) {
     return 0;
 }
 
+int shk_comm_set_timing_only(shk_ctx* ctx, int32_t on) {
+    CHECK_CTX(ctx);
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (c->comm.kind == Comm::NONE || c->comm.nranks <= 1) return fail("timing-only transport needs a communicator of several subdomains");
+    HIPCHK(hipSetDevice(c->device));
+    WAITCHK(c);
+    c->comm.timing_only = on != 0;
+    return 0;
+}
+
+int shk_comm_mark_stalled(shk_ctx* ctx) {
+    CHECK_CTX(ctx);
+    reinterpret_cast<Ctx*>(ctx)->poisoned = true;
+    return 0;
+}
+
+int64_t shk_env_overrides(char* buf, int64_t cap) {
+    const Tunables& T = tunables();
+    if (buf && cap > 0) {
+        const size_t n = std::min<size_t>((size_t)cap - 1, T.overrides.size());
+        std::memcpy(buf, T.overrides.data(), n);
+        buf[n] = '\0';
+    }
+    return T.n_overrides;
+}
+
 int shk_comm_stats(shk_ctx* ctx, int64_t n[4]) {
     CHECK_CTX(ctx);
     if (!n) return fail("null output");
@@ -1016,7 +1071,7 @@ int shk_halo_update(shk_ctx* ctx, int32_t field) {
     if (field < 0 || field >= SHK_FIELD_COUNT || field == SHK_Q) return fail("field id has no ghost segment");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(halo_exchange(c, c->f[field]));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    WAITCHK(c);
     return 0;
 }
 
@@ -1024,14 +1079,14 @@ int shk_sync(shk_ctx* ctx) {
     CHECK_CTX(ctx);
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    WAITCHK(c);
     return 0;
 }
 
 int shk_profile_enable(shk_ctx* ctx, int32_t on) {
     CHECK_CTX(ctx);
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
-    HIPCHK(hipStreamSynchronize(c->stream));
+    WAITCHK(c);
     c->profiling = on != 0;
     return 0;
 }
@@ -1040,7 +1095,7 @@ int shk_profile_read(shk_ctx* ctx, shk_profile* out, int32_t reset) {
     CHECK_CTX(ctx);
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    WAITCHK(c);
     for (size_t i = 0; i < c->ev_used; ++i) {
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, c->ev_pool[i].a, c->ev_pool[i].b));

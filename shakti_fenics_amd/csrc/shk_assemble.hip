@@ -27,6 +27,14 @@ namespace shk {
 #ifndef SHK_ASM_WAVES
 #define SHK_ASM_WAVES 2
 #endif
+// Timing ablations of the assembly kernel (skip the element computation / the slot phase / the field loads: results
+// are WRONG by construction) exist only in probe builds (-DSHK_EXPERIMENTS, `make probe`): the shipping kernel has no
+// such branch.
+#ifdef SHK_EXPERIMENTS
+#define SHK_ABLATE(bit) ((a.ablate & (bit)) != 0)
+#else
+#define SHK_ABLATE(bit) false
+#endif
 constexpr int kAsmFields = 13;   // x, y, N, N_n, b, qx, qy, z_b, z_s, G, melt_n, storage, inputs
 enum { AF_X = 0, AF_Y, AF_N, AF_NN, AF_B, AF_QX, AF_QY, AF_ZB, AF_ZS, AF_G, AF_M, AF_S, AF_I };
 
@@ -239,7 +247,7 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
     ushort4 cvw[R];
 #pragma unroll
     for (int r = 0; r < R; ++r)
-        cvw[r] = (!(a.ablate & 8) && tid + r * T < ncell) ? cellv[tid + r * T] : make_ushort4(0, 0, 0, 0);
+        cvw[r] = (!SHK_ABLATE(8) && tid + r * T < ncell) ? cellv[tid + r * T] : make_ushort4(0, 0, 0, 0);
     for (int i = tid; i <= ns; i += T) sp[i] = a.A.ptr[s0 + i];
     for (int i = tid; i <= nrows; i += T) ip[i] = a.incptr[r0 + i];
     for (int i = tid; i < ninc; i += T) ic[i] = a.inccode[ip0 + i];
@@ -259,7 +267,7 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
 #pragma unroll
         for (int r = 0; r < kStage; ++r) {
             const int i = tid + r * T;
-            if (i < nrows + nhalo && !(a.ablate & 4)) {
+            if (i < nrows + nhalo && !SHK_ABLATE(4)) {
                 const int v = i < nrows ? r0 + i : a.blk_halo[h0 + (i - nrows)];   // own rows: consecutive -> coalesced
                 const double2 xy = a.m.xy[v];
                 sv[r][0] = xy.x;
@@ -274,8 +282,8 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
             const int i = tid + r * T;
             if (i < nrows + nhalo) {
 #pragma unroll
-                for (int k = 0; k < kAsmFields; ++k) fld[k * V + i] = (a.ablate & 4) ? 1.0 + 0.001 * k + 1e-5 * i : sv[r][k];
-                bcf[i] = (a.ablate & 4) ? (uint8_t)0 : sb[r];
+                for (int k = 0; k < kAsmFields; ++k) fld[k * V + i] = SHK_ABLATE(4) ? 1.0 + 0.001 * k + 1e-5 * i : sv[r][k];
+                bcf[i] = SHK_ABLATE(4) ? (uint8_t)0 : sb[r];
             }
         }
     }
@@ -287,8 +295,8 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
     for (int r = 0; r < R; ++r) {
         const int t = tid + r * T;
         if (t < ncell) {
-            const ushort4 cv = (a.ablate & 8) ? cellv[t] : cvw[r];
-            if (a.ablate & 1) {
+            const ushort4 cv = SHK_ABLATE(8) ? cellv[t] : cvw[r];
+            if (SHK_ABLATE(1)) {
 #pragma unroll
                 for (int k = 0; k < 9; ++k) out[r].K[k] = fld[cv.x] + k;
 #pragma unroll
@@ -337,7 +345,7 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
         a.F[v] = sum;
     }
     // ---- phase 2a: one thread per SELL slot of the owned slices ----
-    if (!(a.ablate & 2)) {
+    if (!SHK_ABLATE(2)) {
         // first slot of the block's 2nd .. 4th slice (INT_MAX when absent): a slot's slice by three compares
         const int sp1 = ns > 1 ? sp[1] : 0x7FFFFFFF, sp2 = ns > 2 ? sp[2] : 0x7FFFFFFF, sp3 = ns > 3 ? sp[3] : 0x7FFFFFFF;
 #pragma unroll
@@ -409,8 +417,9 @@ static void fill_asm_args(Ctx* c, double dt, AsmArgs& a) {
     a.cells_max = c->plan.cells_max; a.slices_max = c->plan.slices_max; a.verts_max = c->plan.verts_max;
     a.inc_max = c->plan.max_inc_per_block;
     a.lds_region_a = (int)c->asm_region_a;
-    static const int ablate = getenv("SHK_ASM_ABLATE") ? atoi(getenv("SHK_ASM_ABLATE")) : 0;   // timing experiments only
-    a.ablate = ablate;
+#ifdef SHK_EXPERIMENTS
+    a.ablate = tunables().asm_ablate;   // probe builds only
+#endif
     a.F = c->d_F; a.vals = c->d_vals; a.dinv = c->d_dinv;
     a.p = c->dp;
     a.quad = c->quad;

@@ -10,6 +10,7 @@
 
 #include "../../include/shakti_hip.h"
 #include "shk_plan.h"
+#include "shk_tunables.h"
 
 namespace shk {
 
@@ -287,7 +288,9 @@ struct AsmArgs {
     int verts_max;           // LDS stride V of the staged fields
     int slices_max, inc_max;
     int lds_region_a;        // bytes of the fields / element-tensor region
-    int ablate;              // timing experiments: 1 skip the element computation, 2 the slot phase, 4 the field loads
+#ifdef SHK_EXPERIMENTS
+    int ablate;              // probe builds only: 1 skip the element computation, 2 the slot phase, 4 the field loads
+#endif
     // outputs
     double* F;
     double* vals;
@@ -298,7 +301,7 @@ struct AsmArgs {
 };
 
 inline int32_t sell_fits_cache(int64_t slots, int bytes_per_slot = 12) {   // 8 B value + 4 B column
-    static const int force = getenv("SHK_XCD") ? atoi(getenv("SHK_XCD")) : -1;  // experiment switch: 0 / 1 / 2
+    const int force = tunables().xcd;   // experiment switch: 0 / 1
     if (force >= 0) return force;
     return slots * bytes_per_slot < (int64_t)192 << 20 ? 1 : 0;
 }
@@ -421,6 +424,7 @@ struct Comm {
     std::vector<HaloPlan> plans;             // [0] fine level, [l] multigrid level l (distributed hierarchy)
     int64_t n_exchange = 0, n_allreduce = 0, bytes_exchange = 0, bytes_allreduce = 0;   // message rounds since creation
     int64_t n_overlapped = 0;                // of n_exchange: issued on comm_stream behind an interior pass
+    bool timing_only = false;                // shk_comm_set_timing_only: messages are skipped (results wrong, durations right)
     double* d_sendbuf = nullptr;             // sized for plans[0], the largest
     double* d_recvbuf = nullptr;             // staging of a float vector's ghosts (they travel as doubles)
     double *h_send = nullptr, *h_recv = nullptr, *h_red = nullptr;  // pinned staging (CALLBACK)
@@ -498,6 +502,8 @@ struct Ctx {
     double* d_part_b = nullptr;         // P_COUNT arrays of kMaxParts: partial sums of the boundary passes
     bool assembled = false;
     double assembled_dt = 0.0;
+    bool poisoned = false;   // a host wait hit the RCCL deadline (or shk_comm_mark_stalled): the stream will never drain, so
+                             // shk_destroy must neither synchronise nor free (both would block for ever)
     // profiling
     bool profiling = false;
     struct Ev { hipEvent_t a, b; int phase; };
@@ -515,6 +521,19 @@ struct Ctx {
         return A;
     }
 };
+
+// Setup-time uploads and zero fills are ordered ON THE CONTEXT'S STREAM: it is a non-blocking stream, which null-stream
+// work is not ordered with (round 2 found a null-stream hipMemset overtaking a copy on it).  The upload waits for the
+// copy, so the host array may die as soon as it returns.
+hipError_t wait_stream(Ctx* c);          // hipStreamSynchronize with the RCCL deadline (shk_api.hip)
+inline hipError_t upload_sync(Ctx* c, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return hipSuccess;
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream);
+    return e != hipSuccess ? e : wait_stream(c);
+}
+inline hipError_t zero_async(Ctx* c, void* p, size_t bytes) {
+    return bytes ? hipMemsetAsync(p, 0, bytes, c->stream) : hipSuccess;
+}
 
 // Matrix stream loads: a matrix that cannot stay in the Infinity Cache is read non-temporally so that it does
 // not evict the x vector (measured at 10M rows: -3 % time); a cache-resident one is read normally (non-temporal
@@ -552,6 +571,7 @@ const char* rccl_load();
 int rccl_unique_id(void* out128);
 const char* rccl_init(Ctx* c, int rank, int nranks, const void* id128);
 void comm_destroy(Ctx* c);
+void comm_abort(Ctx* c);                 // poisoned context: ncclCommAbort if the library has it, else the communicator is leaked
 const char* rccl_selftest(Ctx* c);
 hipError_t halo_exchange(Ctx* c, double* vec);                       // level 0
 hipError_t halo_exchange_plan(Ctx* c, const HaloPlan& P, double* vec);

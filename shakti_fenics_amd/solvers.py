@@ -175,14 +175,19 @@ def solve(md):
         storage = md.lake_bdry
 
     ctx, sub = _make_device_state(md, storage)
+    switches = _lib.env_overrides()
+    if switches and md.rank == 0:   # experiment switches (csrc/shk_tunables.h) never act silently
+        print(f"[shakti_fenics_amd] SHK_* experiment switches set in the environment: {switches}", file=sys.stderr, flush=True)
     newton_log, krylov_log = np.zeros(nt, dtype=np.int64), np.zeros(nt, dtype=np.int64)
     i_start = 0
     if restart:
         # the reference has no resume path.  The state after the last saved step is (N, b, q, melt_n)
         # of that frame, and N_n = N: the resumed run continues from exactly that state.  It is bit-identical to the
-        # uninterrupted run when the multigrid's dense coarsest level has <= 512 rows (rebuilt at every solve: meshes up
-        # to ~200k DOF) or with the Jacobi preconditioner; on larger meshes the dense inverse is refreshed every 8th step,
-        # counted from the (re)start, so the two runs agree to the solver tolerance (1e-10 per linear solve), not bit for bit
+        # uninterrupted run ONLY with krylov_warm_start = 0 (md.krylov_warm_start; the default 4 starts each linear solve
+        # from the previous steps' solutions, which a resumed run does not have) AND when the multigrid's dense coarsest
+        # level has <= 512 rows (rebuilt at every solve: meshes up to ~200k DOF) or with the Jacobi preconditioner;
+        # otherwise -- the default warm start, or a larger mesh whose dense inverse is refreshed every 8th step counted
+        # from the (re)start -- the two runs agree to the solver tolerance (fields within 1e-8), not bit for bit
         state = None
         if md.rank == 0:
             prog = np.load(md.results_name + "/progress.npy")
@@ -238,7 +243,12 @@ def solve(md):
             dt.value = np.abs(md.timesteps[i] - md.timesteps[i - 1])
         if stop_after is not None and i > stop_after:
             break
-        info = ctx.step(dt.value)          # Newton solve + q, melt_n, b updates + N_n <- N, all on the GPU
+        try:
+            info = ctx.step(dt.value)      # Newton solve + q, melt_n, b updates + N_n <- N, all on the GPU
+        except _lib.ShaktiCommStall as exc:
+            # a peer died or the ranks diverged: nothing that waits for the device can return any more, so leave the
+            # process with status 1 at once and let the launcher (mpirun / torchrun) tear the job down
+            _lib.exit_on_stall(exc)
         newton_log[i], krylov_log[i] = info.newton_its, info.krylov_its
         if info.krylov_failed:
             ctx.close()

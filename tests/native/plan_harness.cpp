@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <map>
 #include <random>
+#include <string>
 #include <vector>
 
 #include "shk_plan.h"
@@ -36,8 +37,122 @@ static std::map<std::pair<int, int>, double> apply_plan(const AmgLevelPlan& L, c
     return out;
 }
 
+// Mode 2 (plan_harness --parts part0.bin part1.bin ...): the host side of amg_setup_distributed's first level for a
+// P-way decomposition, as shk_amg.hip drives it -- per-subdomain plans, the neighbours' aggregate ids (here looked up
+// through the global vertex ids instead of a ghost exchange), 1024-aligned blocks of the replicated global level with
+// dummy identity rows, coarse_rows of every subdomain concatenated into one SELL pattern, coarsen_onto_global per
+// subdomain.  part file: int64 n_own, n_loc, ne, nglobal; double xy[2 n_loc]; int32 cells[3 ne]; int64 gid[n_loc].
+static int run_parts(int argc, char** argv) {
+    struct Part { int64_t n_own, n_loc, ne; std::vector<double> xy; std::vector<int32_t> cells; std::vector<int64_t> gid; HostPlan P; };
+    const int R = argc - 2;
+    std::vector<Part> parts(R);
+    int64_t nglob = 0;
+    for (int r = 0; r < R; ++r) {
+        Part& q = parts[r];
+        FILE* f = std::fopen(argv[2 + r], "rb");
+        if (!f) return 2;
+        int64_t h[4];
+        if (std::fread(h, 8, 4, f) != 4) return 2;
+        q.n_own = h[0]; q.n_loc = h[1]; q.ne = h[2]; nglob = h[3];
+        q.xy.resize(2 * q.n_loc); q.cells.resize(3 * q.ne); q.gid.resize(q.n_loc);
+        if (std::fread(q.xy.data(), 8, 2 * q.n_loc, f) != (size_t)(2 * q.n_loc) ||
+            std::fread(q.cells.data(), 4, 3 * q.ne, f) != (size_t)(3 * q.ne) ||
+            std::fread(q.gid.data(), 8, q.n_loc, f) != (size_t)q.n_loc) return 2;
+        std::fclose(f);
+        PlanOptions opt;
+        const std::string err = build_plan(q.n_own, q.n_loc, q.ne, q.xy.data(), q.cells.data(), opt, q.P);
+        if (!err.empty()) { std::printf("build_plan FAIL %s\n", err.c_str()); return 1; }
+    }
+    CHECK("build_plans", true);
+    // owner rank and the owner's aggregate of every global vertex
+    std::vector<int32_t> g_rank(nglob, -1), g_agg(nglob, -1);
+    std::vector<int32_t> nc(R), offs(R + 1, 0);
+    for (int r = 0; r < R; ++r) {
+        const Part& q = parts[r];
+        nc[r] = (int32_t)((q.n_own + 3) / 4);
+        offs[r + 1] = offs[r] + ((nc[r] + 1023) / 1024) * 1024;
+        for (int64_t e = 0; e < q.n_own; ++e) {   // external local id e (owned)
+            const int32_t in = q.P.iperm[e];
+            g_rank[q.gid[e]] = r;
+            g_agg[q.gid[e]] = q.P.krank[in] / 4;
+        }
+    }
+    bool owners = true;
+    for (int64_t g = 0; g < nglob; ++g) owners = owners && g_rank[g] >= 0;
+    CHECK("every_vertex_has_an_owner", owners);
+    // every subdomain's rows of the global level, then the pattern all of them agree on
+    std::vector<int32_t> grp(1, 0), gci;
+    std::vector<std::vector<int32_t>> aggs(R), colmaps(R);
+    bool rows_ok = true;
+    for (int r = 0; r < R; ++r) {
+        const Part& q = parts[r];
+        aggs[r].resize(q.n_own);
+        colmaps[r].assign(q.n_loc, -1);
+        for (int64_t i = 0; i < q.n_own; ++i) { aggs[r][i] = q.P.krank[i] / 4; colmaps[r][i] = offs[r] + aggs[r][i]; }
+        for (int64_t j = q.n_own; j < q.n_loc; ++j) {
+            const int64_t g = q.gid[q.P.perm[j]];
+            colmaps[r][j] = offs[g_rank[g]] + g_agg[g];
+        }
+        std::vector<int32_t> rp, ci;
+        const std::string e = coarse_rows(q.P.A, aggs[r], colmaps[r], nc[r], offs[r], rp, ci);
+        rows_ok = rows_ok && e.empty();
+        if (!e.empty()) { std::printf("coarse_rows_error %s\n", e.c_str()); break; }
+        for (int32_t I = 0; I < nc[r]; ++I) {
+            for (int32_t k = rp[I]; k < rp[I + 1]; ++k) gci.push_back(ci[k]);
+            grp.push_back((int32_t)gci.size());
+        }
+        for (int32_t I = offs[r] + nc[r]; I < offs[r + 1]; ++I) { gci.push_back(I); grp.push_back((int32_t)gci.size()); }   // dummy rows
+    }
+    CHECK("coarse_rows", rows_ok);
+    if (!rows_ok) return 1;
+    SellPattern G;
+    std::vector<int32_t> gdiag;
+    const std::string eg = sell_from_csr(offs[R], offs[R], grp, gci, G, gdiag);
+    CHECK("global_level_pattern", eg.empty());
+    if (!eg.empty()) return 1;
+    bool diag_ok = true;
+    for (int32_t I = 0; I < offs[R]; ++I) diag_ok = diag_ok && G.col[gdiag[I]] == I;
+    CHECK("global_level_diag_slots", diag_ok);
+    // transfers: every stored fine entry of every subdomain lands in exactly one slot of G, and with unit fine values the
+    // global level sums to the number of entries of the whole fine matrix
+    bool cover = true, tr_ok = true;
+    double total = 0.0, expect = 0.0;
+    std::vector<int> ghit(G.slots, 0);
+    for (int r = 0; r < R && tr_ok; ++r) {
+        const Part& q = parts[r];
+        AmgLevelPlan L;
+        L.with_ap = true;
+        const std::string e = coarsen_onto_global(q.P.A, aggs[r], colmaps[r], nc[r], offs[r], G, L);
+        tr_ok = e.empty();
+        if (!tr_ok) { std::printf("coarsen_onto_global_error %s\n", e.c_str()); break; }
+        std::vector<int> hit(q.P.A.slots, 0);
+        for (size_t s2 = 0; s2 + 1 < L.gptr.size(); ++s2)
+            for (int32_t k = L.gptr[s2]; k < L.gptr[s2 + 1]; ++k) { hit[L.glist[k]]++; ghit[s2]++; total += 1.0; }
+        for (int i = 0; i < q.P.A.n_rows; ++i) {
+            const int sl = i / kSlice, l = i % kSlice, base = q.P.A.ptr[sl];
+            for (int k = 0; k < q.P.A.rowlen[i]; ++k) cover = cover && hit[base + k * kSlice + l] == 1;
+        }
+        expect += (double)q.P.A.nnz;
+        cover = cover && (int64_t)L.gptr.size() == G.slots + 1;
+        // A*P of the subdomain: columns are global coarse ids
+        for (int32_t cidx : L.AP.col) cover = cover && cidx >= 0 && cidx < offs[R];
+    }
+    CHECK("onto_global_builds", tr_ok);
+    CHECK("onto_global_covers_every_entry_once", cover);
+    CHECK("global_level_sums_to_the_fine_matrix", total == expect);
+    std::vector<int32_t> ident(offs[R]);
+    for (int i = 0; i < offs[R]; ++i) ident[i] = i;
+    std::vector<AmgLevelPlan> rep;
+    PlanOptions o2;
+    o2.amg_cost_nnz = expect;
+    CHECK("replicated_hierarchy_builds", build_amg_levels(G, ident, o2, rep).empty() && !rep.empty() && rep.back().dense);
+    std::printf("global_rows %d\nrep_levels %zu\n", offs[R], rep.size());
+    return fails ? 1 : 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) return 2;
+    if (std::string(argv[1]) == "--parts") return run_parts(argc, argv);
     FILE* f = std::fopen(argv[1], "rb");
     if (!f) return 2;
     int64_t nv = 0, ne = 0;
