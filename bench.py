@@ -249,6 +249,8 @@ def main():
         nk = max(krylov, 1)
         out["message_rounds"] = {"rank": 0, "ghost_exchanges_per_krylov_it": st["exchanges"] / nk,
                                  "allreduces_per_krylov_it": st["allreduces"] / nk,
+                                 "allgathers_per_krylov_it": st["allgathers"] / nk,
+                                 "bytes_allgathered_per_krylov_it": st["bytes_allgathered"] / nk,
                                  "bytes_exchanged_per_krylov_it": st["bytes_exchanged"] / nk,
                                  "bytes_allreduced_per_krylov_it": st["bytes_allreduced"] / nk,
                                  "note": "rounds rank 0 issued inside the timed region (Newton iterations' ghost updates, "

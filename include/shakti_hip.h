@@ -161,8 +161,10 @@ int shk_comm_set_timing_only(shk_ctx* ctx, int32_t on);
  * would block behind the stalled collective.  The process is expected to exit non-zero right after. */
 int shk_comm_mark_stalled(shk_ctx* ctx);
 /* Message rounds this context has issued since creation: n[0] ghost exchanges, n[1] all-reduces, n[2] bytes sent in
- * exchanges, n[3] bytes all-reduced (per rank).  Differences around a solve give rounds per Krylov iteration. */
-int shk_comm_stats(shk_ctx* ctx, int64_t n[4]);
+ * exchanges, n[3] bytes all-reduced (per rank), n[4] in-place all-gathers (the replicated multigrid level's right-hand
+ * side, once per cycle, and its operator values, once per Newton iteration), n[5] bytes received in them.  Differences
+ * around a solve give rounds per Krylov iteration. */
+int shk_comm_stats(shk_ctx* ctx, int64_t n[6]);
 /* Interior / boundary split of the finest level's sweeps (several subdomains; off unless the environment sets
  * SHK_OVERLAP=1 -- DESIGN.md section 5 says why): the ghost
  * exchange of the two Krylov products and of the finest smoothing sweep travels on a second stream while the SELL
@@ -177,6 +179,10 @@ int shk_halo_update(shk_ctx* ctx, int32_t field);
  * and returns how many there are; 0 = the run uses the defaults every committed measurement was taken with.  None of
  * them changes what is computed.  buf may be NULL. */
 int64_t shk_env_overrides(char* buf, int64_t cap);
+/* Set one of those switches from code instead of the environment (tests, probes): name as in the environment
+ * ("SHK_AMG_ALPHA"), value as its text; value NULL = back to the default.  Process-wide; contexts read the switches when
+ * they are created (a few tuning values at use).  Recorded in shk_env_overrides like an environment override. */
+int shk_tunable_set(const char* name, const char* value);
 
 int shk_default_params(shk_params* p);
 int shk_set_params(shk_ctx* ctx, const shk_params* p);

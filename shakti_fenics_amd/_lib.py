@@ -67,7 +67,7 @@ EXPORTS = (
     "shk_assemble", "shk_get_residual", "shk_csr_nnz", "shk_get_csr", "shk_linear_solve", "shk_spmv",
     "shk_newton_solve", "shk_update_explicit", "shk_step", "shk_sync", "shk_profile_enable",
     "shk_profile_read", "shk_time_kernel", "shk_plan_stats", "shk_set_halo", "shk_comm_unique_id",
-    "shk_comm_init_rccl", "shk_comm_init_callbacks", "shk_comm_selftest", "shk_comm_set_timing_only", "shk_comm_mark_stalled", "shk_env_overrides", "shk_comm_stats", "shk_comm_overlap", "shk_halo_update", "shk_interp_regular_grid",
+    "shk_comm_init_rccl", "shk_comm_init_callbacks", "shk_comm_selftest", "shk_comm_set_timing_only", "shk_comm_mark_stalled", "shk_env_overrides", "shk_tunable_set", "shk_comm_stats", "shk_comm_overlap", "shk_halo_update", "shk_interp_regular_grid",
     "shk_points_in_polygon",
 )
 
@@ -128,6 +128,7 @@ def load():
         "shk_comm_set_timing_only": ([vp, i32], C.c_int),
         "shk_comm_mark_stalled": ([vp], C.c_int),
         "shk_env_overrides": ([C.c_char_p, i64], i64),
+        "shk_tunable_set": ([C.c_char_p, C.c_char_p], C.c_int),
         "shk_interp_regular_grid": ([C.c_int, i64, vp, vp, i64, i64, vp, vp, vp, i32, vp], C.c_int),
         "shk_points_in_polygon": ([C.c_int, i64, vp, vp, i64, vp, vp], C.c_int),
     }
@@ -144,6 +145,27 @@ def env_overrides() -> str:
     buf = C.create_string_buffer(4096)
     load().shk_env_overrides(buf, 4096)
     return buf.value.decode()
+
+
+class tunables:
+    """Context manager for tests and probes: experiment switches set from code for the duration of a block
+    (`with _lib.tunables(SHK_AMG_ALPHA=1.8): ctx = ShaktiHip(...)`), then back to their defaults.  Process-wide."""
+
+    def __init__(self, **kw):
+        self.kw = {k: str(v) for k, v in kw.items()}
+
+    def __enter__(self):
+        lib = load()
+        for k, v in self.kw.items():
+            if lib.shk_tunable_set(k.encode(), v.encode()) != 0:
+                raise ShaktiHipError(lib.shk_last_error().decode())
+        return self
+
+    def __exit__(self, *exc):
+        lib = load()
+        for k in self.kw:   # back to what the environment says, else to the default
+            lib.shk_tunable_set(k.encode(), os.environ[k].encode() if k in os.environ else None)
+        return False
 
 
 def rccl_unique_id() -> bytes:
@@ -388,9 +410,10 @@ class ShaktiHip:
         self._check(self.lib.shk_comm_mark_stalled(self._h))
 
     def comm_stats(self) -> dict:
-        n = (C.c_int64 * 4)()
+        n = (C.c_int64 * 6)()
         self._check(self.lib.shk_comm_stats(self._h, n))
-        return dict(exchanges=int(n[0]), allreduces=int(n[1]), bytes_exchanged=int(n[2]), bytes_allreduced=int(n[3]))
+        return dict(exchanges=int(n[0]), allreduces=int(n[1]), bytes_exchanged=int(n[2]), bytes_allreduced=int(n[3]),
+                    allgathers=int(n[4]), bytes_allgathered=int(n[5]))
 
     def comm_overlap(self) -> dict:
         """Interior / boundary split of the finest level's sweeps (several subdomains): see shk_comm_overlap."""

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(kBlock) void k_bgj_update(int n, int k0, int b, dou
 }
 // scratch: >= (2 n + kGjB) * kGjB doubles
 static void dense_invert_big(Ctx* c, int n, const double* A, double* inv, double* scratch) {
-    if (tunables().gj_pivotwise)   // cross-check switch { dense_invert_pivotwise(c, n, A, inv, scratch); return; }
+    if (tunables().gj_pivotwise) { dense_invert_pivotwise(c, n, A, inv, scratch); return; }   // cross-check switch
     (void)hipMemcpyAsync(inv, A, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
     double *Cp = scratch, *Rp = scratch + (size_t)n * kGjB, *Dinv = Rp + (size_t)n * kGjB;
     const int gv = (n + kBlock - 1) / kBlock, gt = (n + 63) / 64;
@@ -402,11 +402,21 @@ struct AmgFirstArgs {
     float* xo;
     float omega, alpha;
     const int* done;
+    // decomposed level with frozen ghosts: ghost column g of the iterate gets alpha * e[ghost_col[g]] (in xo and, for the
+    // levels whose later sweeps alternate between two vectors, in xo2 as well); nullptr / 0 otherwise
+    const int32_t* ghost_col;
+    int32_t n_ghost;
+    float* xo2;
 };
 template <bool FINE, class TR>
 __global__ __launch_bounds__(kBlock) void k_amg_first(const AmgFirstArgs<TR> a) {
     if (*a.done) return;
     const int lane = threadIdx.x & 63;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n_ghost; i += gridDim.x * kBlock) {
+        const float v = a.alpha * a.e[a.ghost_col[i]];
+        a.xo[a.AP.n_rows + i] = v;
+        if (a.xo2) a.xo2[a.AP.n_rows + i] = v;
+    }
     for (SliceLoop it(a.AP, wave_index()); it.valid(); it.next()) {
         const int row = min(it.s * kSlice + lane, a.AP.n_rows - 1);
         const int ag = a.agg[row];
@@ -893,14 +903,17 @@ hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense, bool d
         if (X.with_ap)
             launch_galerkin<float>(c, 1, X.ap_slots, X.ap_gptr, X.ap_glist, fine, X.ap_vals);
         if (X.onto_global) {
-            // my rows of the replicated global level (zeros elsewhere), completed by one all-reduce; then the
-            // replicated hierarchy refreshes itself from it, identically on every subdomain
+            // my rows of the replicated global level -- whole SELL slices, since every subdomain's block is a multiple of
+            // 1024 rows: the slots [rep_val_off[me], rep_val_off[me + 1]) of its value array -- written in place (float,
+            // summed in double like every Galerkin product); ONE in-place all-gather brings in the other subdomains'
+            // slices, then the replicated hierarchy refreshes itself from it, identically on every subdomain.
+            // (Rounds 1-2 all-reduced the whole array in double, zero outside each subdomain's slices: 2 P times the bytes.)
             AmgHierarchy& R = *H.rep;
-            launch_galerkin<double>(c, 0, R.t_slots, X.gptr, X.glist, fine, H.rep_gtmp);
-            hipError_t e = allreduce_buffer(c, H.rep_gtmp, H.rep_gtmp, (size_t)R.t_slots);
+            const int me = c->comm.rank;
+            const int64_t s0 = H.rep_val_off[me] / (int64_t)sizeof(float), s1 = H.rep_val_off[me + 1] / (int64_t)sizeof(float);
+            launch_galerkin<float>(c, 0, s1 - s0, X.gptr + s0, X.glist, fine, R.t_vals + s0);
+            hipError_t e = allgather_blocks(c, R.t_vals, H.rep_val_off);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(k_narrow, dim3(small_grid(R.t_slots)), dim3(kBlock), 0, c->stream, R.t_slots,
-                               (const double*)H.rep_gtmp, R.t_vals);
             hipLaunchKernelGGL(k_diag_inv, dim3(small_grid(H.rep_n)), dim3(kBlock), 0, c->stream, H.rep_n, R.t_diag,
                                (const float*)R.t_vals, R.t_dinv);
             if ((e = amg_numeric_setup(c, R, refresh_dense, true)) != hipSuccess) return e;
@@ -963,7 +976,8 @@ static size_t tail_start(const AmgHierarchy& H) {
     return lt;
 }
 
-__global__ __launch_bounds__(kBlock) void k_amg_restrict4(int32_t n, const double* __restrict__ r, const RestrictArgs ra,
+template <class TR>
+__global__ __launch_bounds__(kBlock) void k_amg_restrict4(int32_t n, const TR* __restrict__ r, const RestrictArgs ra,
                                                           const int* __restrict__ done) {
     __shared__ double rbuf0[kBlock];
     __shared__ float rbuf[kFusedRestrict - 1][256];
@@ -971,7 +985,7 @@ __global__ __launch_bounds__(kBlock) void k_amg_restrict4(int32_t n, const doubl
     const int ngroups = (n + kBlock - 1) / kBlock;
     for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
         const int i = g * kBlock + threadIdx.x;
-        fused_restrict(ra, g, i < n ? r[i] : 0.0, rbuf0, rbuf);
+        fused_restrict(ra, g, i < n ? (double)r[i] : 0.0, rbuf0, rbuf);
     }
 }
 
@@ -986,7 +1000,7 @@ static RestrictArgs amg_restrict_args(const AmgHierarchy& H) {
         if (!X.members_kd || !X.kd_pos) break;
         ra.members[l] = reinterpret_cast<const int4*>(X.members_kd);
         ra.pos[l] = X.kd_pos;
-        ra.rc[l] = X.dense ? H.cr : X.onto_global ? H.rep_rloc : H.lv[l + 1].r;
+        ra.rc[l] = X.dense ? H.cr : X.onto_global ? H.rep_rglob + H.rep_row0 : H.lv[l + 1].r;
         ra.nc[l] = X.n_coarse;
         ra.nlev = (int)l + 1;
     }
@@ -1022,8 +1036,10 @@ static hipError_t launch_post_split(Ctx* c, const DevSell& A, const float* vals,
     return hipSuccess;
 }
 
-// z = M^-1 r : one V(0,2) cycle.  r and z have the fine level's length; r is not modified.
-hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
+// z = M^-1 r : one V(0,2) cycle.  r and z have the fine level's length; r is not modified.  TR: double for a context's
+// own hierarchies (the Krylov vector), float for the replicated hierarchy (the gathered right-hand side).
+template <class TR>
+static hipError_t amg_vcycle_t(Ctx* c, AmgHierarchy& H, const TR* rin, float* zout) {
     const int32_t n_top = H.topA.n_rows, ncol_top = H.topA.n_cols;
     const size_t nx = H.xf.size();  // levels 0..nx-1 are sparse, level nx is the dense coarsest
     const int* done = &c->d_state->done;
@@ -1051,14 +1067,14 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
         // one launch for four levels while a workgroup has few groups to walk through (each costs a memory round
         // trip and four barriers); measured at 1M rows: 46.9 -> 45.4 ms/step, at 10M rows the plain cascade wins
         if (ra.nlev > 1)
-            hipLaunchKernelGGL(k_amg_restrict4, dim3(std::min((n_top + kBlock - 1) / kBlock, 2048)), dim3(kBlock),
+            hipLaunchKernelGGL(k_amg_restrict4<TR>, dim3(std::min((n_top + kBlock - 1) / kBlock, 2048)), dim3(kBlock),
                                0, c->stream, n_top, rin, ra, done);
         for (size_t l = ra.nlev > 1 ? (size_t)ra.nlev : 0; l < lt; ++l) {
             const AmgXfer& X = H.xf[l];
-            float* rc = X.dense ? H.cr : X.onto_global ? H.rep_rloc : H.lv[l + 1].r;
+            float* rc = X.dense ? H.cr : X.onto_global ? H.rep_rglob + H.rep_row0 : H.lv[l + 1].r;
             const dim3 g(small_grid(X.n_coarse));
             if (l == 0)
-                hipLaunchKernelGGL(k_amg_restrict<double>, g, dim3(kBlock), 0, c->stream, X.n_coarse, X.members, rin, rc, done);
+                hipLaunchKernelGGL(k_amg_restrict<TR>, g, dim3(kBlock), 0, c->stream, X.n_coarse, X.members, rin, rc, done);
             else
                 hipLaunchKernelGGL(k_amg_restrict<float>, g, dim3(kBlock), 0, c->stream, X.n_coarse, X.members,
                                    (const float*)H.lv[l].r, rc, done);
@@ -1066,15 +1082,10 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
     }
     const AmgXfer& XL = H.xf[nx - 1];
     if (H.rep) {
-        // gather the replicated level's right-hand side (my rows, zeros elsewhere, one all-reduce) and run the rest
-        // of the cycle redundantly on every subdomain
-        {
-            PhaseTimer t(c, SHK_PH_AMG_COARSE);
-            hipLaunchKernelGGL(k_coarse_scatter, dim3(small_grid(H.rep_n)), dim3(kBlock), 0, c->stream, XL.n_coarse,
-                               H.rep_row0, H.rep_n, H.rep_rloc, H.rep_rglob, done);
-        }
-        if ((e = allreduce_buffer(c, H.rep_rglob, H.rep_rglob, (size_t)H.rep_n)) != hipSuccess) return e;
-        if ((e = amg_vcycle(c, *H.rep, H.rep_rglob, H.rep_xglob)) != hipSuccess) return e;
+        // the restriction has written my block of the replicated level's right-hand side in place; one in-place
+        // all-gather of floats brings in the others', and the rest of the cycle runs redundantly on every subdomain
+        if ((e = allgather_blocks(c, H.rep_rglob, H.rep_rhs_off)) != hipSuccess) return e;
+        if ((e = amg_vcycle_t<float>(c, *H.rep, H.rep_rglob, H.rep_xglob)) != hipSuccess) return e;
     }
     TailArgs ta;
     ta.nlev = (int)(nx - lt);
@@ -1134,9 +1145,16 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
         // exchange its result first (a smaller message than exchanging the prolongated vector); the replicated
         // level's result is complete on every subdomain
         const bool fused = X.with_ap && !X.dense && (!H.distributed || X.onto_global || (int)(l + 1) < H.halo_levels);
+        // frozen-ghost smoothing (AmgHierarchy::frozen_ghosts): the first sweep also writes this level's ghost columns,
+        // alpha * e[coarse column of the ghost], and no sweep of the level exchanges
+        const bool frozen = halo && fused && ((H.frozen_mask >> std::min<size_t>(l, 30)) & 1u) && X.ghost_col != nullptr;
         const float* e_cols = X.onto_global ? H.rep_xglob : ec;
         const int32_t agg_off = X.onto_global ? H.rep_row0 : 0;
-        if (fused && H.distributed && !X.onto_global &&
+        // (a frozen coarser level whose bit of e_exchange_mask is clear keeps the ghosts its first sweep wrote -- the
+        //  prolongated correction of the level below it, without that level's smoothing -- and sends nothing)
+        const bool coarser_frozen = l + 1 < nx && ((H.frozen_mask >> std::min<size_t>(l + 1, 30)) & 1u) && H.xf[l + 1].ghost_col != nullptr;
+        const bool send_e = !coarser_frozen || ((H.e_exchange_mask >> std::min<size_t>(l + 1, 30)) & 1u);
+        if (fused && H.distributed && !X.onto_global && send_e &&
             (e = halo_exchange_plan_f32(c, c->comm.plans[H.plan_of[l + 1]], H.lv[l + 1].x2)) != hipSuccess)
             return e;
         const DevSell A = level_sell(c, H, l);
@@ -1144,15 +1162,17 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
         if (l == 0) {
             // level 0: right-hand side = the Krylov vector (double); the iterate and the result are float.
             // A replicated hierarchy's top level is a coarse level of the whole cycle: four sweeps, like its peers.
+            bool split_done = false;
             const float w2_fine = w2;
             const bool four = H.top_four && H.coarse4;
             const float omega = four ? (float)(H.c4[0] / l4) : w1;
             const float w2 = four ? (float)(H.c4[1] / l4) : w2_fine;
             if (fused) {
-                AmgFirstArgs<double> f{DevSell{X.n_fine, X.n_coarse_cols, X.ap_nslice, sell_fits_cache(X.ap_slots, kAmgSlotBytes),
-                                               X.ap_ptr, X.ap_col, X.ap_rowlen, X.ap_cbase, X.ap_ptr16, X.ap_col16},
-                                       X.ap_vals, H.top_dinv, rin, e_cols, X.agg, agg_off, H.x0, omega, alpha, done};
-                launch_phase(c, ph(SHK_PH_AMG_FIRST), k_amg_first<true, double>, g, dim3(kBlock), 0, f);
+                AmgFirstArgs<TR> f{DevSell{X.n_fine, X.n_coarse_cols, X.ap_nslice, sell_fits_cache(X.ap_slots, kAmgSlotBytes),
+                                           X.ap_ptr, X.ap_col, X.ap_rowlen, X.ap_cbase, X.ap_ptr16, X.ap_col16},
+                                   X.ap_vals, H.top_dinv, rin, e_cols, X.agg, agg_off, H.x0, omega, alpha, done,
+                                   frozen ? X.ghost_col : nullptr, frozen ? X.n_ghost : 0, nullptr};
+                launch_phase(c, ph(SHK_PH_AMG_FIRST), k_amg_first<true, TR>, g, dim3(kBlock), 0, f);
             } else {
                 {
                     PhaseTimer t(c, ph(SHK_PH_AMG_COARSE));
@@ -1162,10 +1182,14 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
                 if (halo && (e = halo_exchange_plan_f32(c, *HP, zout)) != hipSuccess) return e;
                 launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)zout, H.x0, omega, done, ph(SHK_PH_AMG_FINE));
             }
-            if (halo && c->overlap && H.plan_of[0] == 0 && A.ptr == c->d_sell_ptr) {
-                if ((e = launch_post_split(c, A, H.top_vals, H.top_dinv, rin, H.x0, zout, w2, done)) != hipSuccess) return e;
-            } else {
-                if (halo && (e = halo_exchange_plan_f32(c, *HP, H.x0)) != hipSuccess) return e;
+            if constexpr (sizeof(TR) == sizeof(double)) {
+                if (halo && !frozen && c->overlap && H.plan_of[0] == 0 && A.ptr == c->d_sell_ptr) {
+                    if ((e = launch_post_split(c, A, H.top_vals, H.top_dinv, rin, H.x0, zout, w2, done)) != hipSuccess) return e;
+                    split_done = true;
+                }
+            }
+            if (!split_done) {
+                if (halo && !frozen && (e = halo_exchange_plan_f32(c, *HP, H.x0)) != hipSuccess) return e;
                 launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)H.x0, zout, w2, done, ph(SHK_PH_AMG_FINE));
             }
             if (four) {
@@ -1185,7 +1209,8 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
             if (fused) {
                 AmgFirstArgs<float> f{DevSell{X.n_fine, X.n_coarse_cols, X.ap_nslice, sell_fits_cache(X.ap_slots, kAmgSlotBytes),
                                               X.ap_ptr, X.ap_col, X.ap_rowlen, X.ap_cbase, X.ap_ptr16, X.ap_col16},
-                                      X.ap_vals, L.dinv, L.r, e_cols, X.agg, agg_off, L.x, lw1, alpha, done};
+                                      X.ap_vals, L.dinv, L.r, e_cols, X.agg, agg_off, L.x, lw1, alpha, done,
+                                      frozen ? X.ghost_col : nullptr, frozen ? X.n_ghost : 0, L.x2};
                 PhaseTimer t(c, ph_level(l));
                 hipLaunchKernelGGL((k_amg_first<false, float>), g, dim3(kBlock), 0, c->stream, f);
             } else {
@@ -1200,8 +1225,8 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
                 PhaseTimer t(c, ph_level(l));
                 launch_post<false>(c, A, L.vals, L.dinv, (const float*)L.r, (const float*)L.x2, L.x, lw1, done);
             }
-            if (halo && (e = halo_exchange_plan_f32(c, *HP, L.x)) != hipSuccess) return e;
-            if (halo && fused && more) {
+            if (halo && !frozen && (e = halo_exchange_plan_f32(c, *HP, L.x)) != hipSuccess) return e;
+            if (halo && !frozen && fused && more) {
                 // The third sweep reads x2, whose ghost segment no exchange of THIS cycle has filled when the first
                 // sweep ran on A*P (it would hold the previous cycle's values: the preconditioner would stop being a
                 // function of its input, and BiCGStab breaks down).  Give it the ghosts just received for x.
@@ -1252,6 +1277,8 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
     }
     return hipSuccess;
 }
+
+hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) { return amg_vcycle_t<double>(c, H, rin, zout); }
 
 // ------------------------------------------------------------------ distributed setup (collective)
 // One integer per row of a level travels as a double through that level's halo plan.
@@ -1317,6 +1344,9 @@ int amg_setup_distributed(Ctx* c, std::string& err) {
     if ((size_t)2 * c->n_loc < (size_t)R) { err = "too many ranks for the staging buffer"; return -1; }
     AmgHierarchy& H = c->amg_dist;
     H.distributed = true;
+    // SHK_AMG_GHOST_EXCHANGE = bit mask of the decomposed levels that KEEP the exchange after their first sweep
+    H.frozen_mask = tunables().amg_ghost_exchange >= 0 ? ~(uint32_t)tunables().amg_ghost_exchange : H.frozen_mask;
+    if (tunables().amg_e_exchange >= 0) H.e_exchange_mask = (uint32_t)tunables().amg_e_exchange;
     if (tunables().amg_halo_levels >= 0) H.halo_levels = tunables().amg_halo_levels;
     // first level gathered and replicated on every subdomain: the first whose global size is at most this (0: never)
     // (default 200 000: level 3 of a 10M-row mesh, level 2 at 1M rows; the gathered right-hand side is then at most
@@ -1361,7 +1391,10 @@ int amg_setup_distributed(Ctx* c, std::string& err) {
             // the gap): the replicated hierarchy aggregates runs of 4 GLOBAL rows level after level, and only an
             // aligned block keeps those runs inside the subdomain's own k-d cells (unaligned, every aggregate
             // straddles two cells and the cycle needs twice the iterations).
-            for (int r = 0; r < R; ++r) offs[r + 1] = offs[r] + ((all_nc[r] + 1023) / 1024) * 1024;
+            // ... and all blocks have the SAME size (that of the largest subdomain's share; recursive bisection balances
+            // the subdomains to +-1 vertex anyway): the right-hand side is then gathered by one ncclAllGather in place.
+            const int32_t blk = ((maxnc + 1023) / 1024) * 1024;
+            for (int r = 0; r < R; ++r) offs[r + 1] = offs[r] + blk;
         }
         const int32_t nc_own = all_nc[me];
         const HaloPlan& P = m.plans[cur_plan];
@@ -1425,10 +1458,18 @@ int amg_setup_distributed(Ctx* c, std::string& err) {
             perr = coarsen(*Af, agg, colmap, nc_own, ncols, next_dense, plans.back());
         }
         if (!perr.empty()) { err = perr; return -1; }
+        // coarse column of every ghost column of this level (frozen-ghost smoothing)
+        plans.back().ghost_col.assign(colmap.begin() + n_own, colmap.end());
         H.plan_of.push_back((int)cur_plan);
         if (next_rep) {
             H.rep_row0 = offs[me];
             H.rep_n = offs[R];
+            H.rep_rhs_off.resize(R + 1);
+            H.rep_val_off.resize(R + 1);
+            for (int r = 0; r <= R; ++r) {
+                H.rep_rhs_off[r] = (int64_t)offs[r] * (int64_t)sizeof(float);
+                H.rep_val_off[r] = (int64_t)G.ptr[offs[r] / kSlice] * (int64_t)sizeof(float);   // blocks are whole slices
+            }
             break;
         }
         if (next_dense) {

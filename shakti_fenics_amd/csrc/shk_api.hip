@@ -224,12 +224,17 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
             if ((e = upload(c, &X.ap_glist, LP.ap_glist)) != hipSuccess) return e;
             if ((e = dev_alloc(c, &X.ap_vals, (size_t)X.ap_slots)) != hipSuccess) return e;
         }
+        if (!LP.ghost_col.empty()) {
+            X.n_ghost = (int32_t)LP.ghost_col.size();
+            if ((e = upload(c, &X.ghost_col, LP.ghost_col)) != hipSuccess) return e;
+        }
         if (LP.onto_global) {
             if (l + 1 != nx) return hipErrorInvalidValue;  // the replicated level ends the distributed part
-            if ((e = dev_alloc(c, &H.rep_rloc, std::max<size_t>(64, (size_t)LP.n_coarse))) != hipSuccess) return e;
-            if ((e = dev_alloc(c, &H.rep_rglob, std::max<size_t>(64, (size_t)LP.n_coarse_cols))) != hipSuccess) return e;
-            if ((e = dev_alloc(c, &H.rep_xglob, std::max<size_t>(64, (size_t)LP.n_coarse_cols))) != hipSuccess) return e;
-            if ((e = dev_alloc(c, &H.rep_gtmp, LP.gptr.size())) != hipSuccess) return e;
+            // (the dummy rows that pad every subdomain's block of the gathered right-hand side stay zero for ever)
+            const size_t ng = std::max<size_t>(64, (size_t)LP.n_coarse_cols);
+            if ((e = dev_alloc(c, &H.rep_rglob, ng)) != hipSuccess) return e;
+            if ((e = zero_async(c, H.rep_rglob, ng * sizeof(float))) != hipSuccess) return e;
+            if ((e = dev_alloc(c, &H.rep_xglob, ng)) != hipSuccess) return e;
         } else if (!LP.dense) {
             if (l + 1 >= nx) return hipErrorInvalidValue;  // a hierarchy must end on a dense level
             AmgLevel& L = H.lv[l + 1];
@@ -1041,19 +1046,27 @@ int shk_comm_mark_stalled(shk_ctx* ctx) {
 
 int64_t shk_env_overrides(char* buf, int64_t cap) {
     const Tunables& T = tunables();
+    const std::string o = T.overrides();
     if (buf && cap > 0) {
-        const size_t n = std::min<size_t>((size_t)cap - 1, T.overrides.size());
-        std::memcpy(buf, T.overrides.data(), n);
+        const size_t n = std::min<size_t>((size_t)cap - 1, o.size());
+        std::memcpy(buf, o.data(), n);
         buf[n] = '\0';
     }
-    return T.n_overrides;
+    return (int64_t)T.set.size();
 }
 
-int shk_comm_stats(shk_ctx* ctx, int64_t n[4]) {
+int shk_tunable_set(const char* name, const char* value) {
+    if (!name) return fail("null switch name");
+    if (!tunable_set(name, value)) return fail(std::string("unknown experiment switch: ") + name);
+    return 0;
+}
+
+int shk_comm_stats(shk_ctx* ctx, int64_t n[6]) {
     CHECK_CTX(ctx);
     if (!n) return fail("null output");
     const Comm& m = reinterpret_cast<Ctx*>(ctx)->comm;
     n[0] = m.n_exchange; n[1] = m.n_allreduce; n[2] = m.bytes_exchange; n[3] = m.bytes_allreduce;
+    n[4] = m.n_allgather; n[5] = m.bytes_allgather;
     return 0;
 }
 

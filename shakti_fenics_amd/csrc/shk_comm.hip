@@ -30,6 +30,7 @@ struct RcclApi {
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;   // optional
 };
@@ -52,6 +53,7 @@ const char* rccl_load() {
     SYM(Send, "ncclSend");
     SYM(Recv, "ncclRecv");
     SYM(AllReduce, "ncclAllReduce");
+    SYM(AllGather, "ncclAllGather");
     SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
     g_rccl.CommGetAsyncError = reinterpret_cast<decltype(g_rccl.CommGetAsyncError)>(dlsym(h, "ncclCommGetAsyncError"));
@@ -152,11 +154,11 @@ void comm_destroy(Ctx* c) {
     c->comm.kind = Comm::NONE;
 }
 
-template <class T>
+template <class T, class TB>
 __global__ __launch_bounds__(kBlock) void k_pack(int64_t n, const int32_t* __restrict__ idx,
-                                                 const T* __restrict__ v, double* __restrict__ buf) {
+                                                 const T* __restrict__ v, TB* __restrict__ buf) {
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
-        buf[i] = (double)v[idx[i]];
+        buf[i] = (TB)v[idx[i]];
 }
 __global__ __launch_bounds__(kBlock) void k_unpack_f32(int64_t n, const double* __restrict__ buf,
                                                        float* __restrict__ ghost) {
@@ -164,20 +166,24 @@ __global__ __launch_bounds__(kBlock) void k_unpack_f32(int64_t n, const double* 
         ghost[i] = (float)buf[i];
 }
 
-// Send the packed buffer, receive the neighbours' into `recv` (device memory, neighbour-major).
-static hipError_t exchange_packed(Ctx* c, const HaloPlan& P, double* recv, hipStream_t stream) {
+// Send the packed buffer, receive the neighbours' into `recv` (device memory, neighbour-major).  T = double, or float
+// over RCCL (a float vector's ghosts then land straight in its ghost segment; the host-staged callbacks carry doubles).
+template <class T>
+static hipError_t exchange_packed(Ctx* c, const HaloPlan& P, T* recv, hipStream_t stream) {
     Comm& m = c->comm;
     const int64_t nsend = P.send_ptr.back(), nrecv = P.recv_ptr.back();
     m.n_exchange += 1;
-    m.bytes_exchange += nsend * (int64_t)sizeof(double);
+    m.bytes_exchange += nsend * (int64_t)sizeof(T);
     if (m.timing_only) return hipSuccess;   // measurement aid: the message is skipped, `recv` keeps what it held
     if (m.kind == Comm::RCCL) {
         ncclComm_t comm = reinterpret_cast<ncclComm_t>(m.nccl);
+        const ncclDataType_t dt = sizeof(T) == sizeof(double) ? ncclDouble : ncclFloat;
+        const T* sendbuf = reinterpret_cast<const T*>(m.d_sendbuf);
         g_rccl.GroupStart();
         for (size_t k = 0; k < P.nbr.size(); ++k) {
             const int64_t ns = P.send_ptr[k + 1] - P.send_ptr[k], nr = P.recv_ptr[k + 1] - P.recv_ptr[k];
-            if (ns > 0) g_rccl.Send(m.d_sendbuf + P.send_ptr[k], (size_t)ns, ncclDouble, P.nbr[k], comm, stream);
-            if (nr > 0) g_rccl.Recv(recv + P.recv_ptr[k], (size_t)nr, ncclDouble, P.nbr[k], comm, stream);
+            if (ns > 0) g_rccl.Send(sendbuf + P.send_ptr[k], (size_t)ns, dt, P.nbr[k], comm, stream);
+            if (nr > 0) g_rccl.Recv(recv + P.recv_ptr[k], (size_t)nr, dt, P.nbr[k], comm, stream);
         }
         ncclResult_t r = g_rccl.GroupEnd();
         if (r == ncclSuccess && g_rccl.CommGetAsyncError) {   // a transport failure must not surface later as a hung solve
@@ -186,7 +192,8 @@ static hipError_t exchange_packed(Ctx* c, const HaloPlan& P, double* recv, hipSt
         }
         return r == ncclSuccess ? hipSuccess : hipErrorUnknown;
     }
-    // CALLBACK: host-staged
+    // CALLBACK: host-staged, doubles only
+    if constexpr (sizeof(T) != sizeof(double)) return hipErrorInvalidValue;
     hipError_t e = hipSuccess;
     if (nsend > 0)
         e = hipMemcpyAsync(m.h_send, m.d_sendbuf, (size_t)nsend * sizeof(double), hipMemcpyDeviceToHost, stream);
@@ -197,7 +204,7 @@ static hipError_t exchange_packed(Ctx* c, const HaloPlan& P, double* recv, hipSt
                       P.recv_ptr.data()) != 0)
         return hipErrorUnknown;
     if (nrecv > 0)
-        e = hipMemcpyAsync(recv, m.h_recv, (size_t)nrecv * sizeof(double), hipMemcpyHostToDevice, stream);
+        e = hipMemcpyAsync((void*)recv, m.h_recv, (size_t)nrecv * sizeof(double), hipMemcpyHostToDevice, stream);
     return e;
 }
 
@@ -207,19 +214,25 @@ static hipError_t exchange_f64(Ctx* c, const HaloPlan& P, double* vec, hipStream
     const int64_t nsend = P.send_ptr.back();
     if (nsend > 0) {
         const int g = (int)std::min<int64_t>((nsend + kBlock - 1) / kBlock, 1024);
-        hipLaunchKernelGGL(k_pack<double>, dim3(g), dim3(kBlock), 0, stream, nsend, P.d_send_idx, vec, m.d_sendbuf);
+        hipLaunchKernelGGL((k_pack<double, double>), dim3(g), dim3(kBlock), 0, stream, nsend, P.d_send_idx, vec, m.d_sendbuf);
     }
     return exchange_packed(c, P, vec + P.n_own, stream);
 }
-// The same for a float vector of the multigrid preconditioner: values travel as doubles (the volume is a few
-// thousand entries) and are narrowed again on arrival.
+// The same for a float vector of the multigrid preconditioner.  Over RCCL the values travel as floats and land
+// straight in the ghost segment (one pack kernel, no unpack); through the host-staged callbacks, whose ABI carries
+// doubles, they are widened on the way out and narrowed again on arrival.
 static hipError_t exchange_f32(Ctx* c, const HaloPlan& P, float* vec, hipStream_t stream) {
     Comm& m = c->comm;
     const int64_t nsend = P.send_ptr.back(), nrecv = P.recv_ptr.back();
-    if (nsend > 0) {
-        const int g = (int)std::min<int64_t>((nsend + kBlock - 1) / kBlock, 1024);
-        hipLaunchKernelGGL(k_pack<float>, dim3(g), dim3(kBlock), 0, stream, nsend, P.d_send_idx, vec, m.d_sendbuf);
+    const int gp = (int)std::min<int64_t>((nsend + kBlock - 1) / kBlock, 1024);
+    if (m.kind == Comm::RCCL) {
+        if (nsend > 0)
+            hipLaunchKernelGGL((k_pack<float, float>), dim3(gp), dim3(kBlock), 0, stream, nsend, P.d_send_idx, vec,
+                               reinterpret_cast<float*>(m.d_sendbuf));
+        return exchange_packed(c, P, vec + P.n_own, stream);
     }
+    if (nsend > 0)
+        hipLaunchKernelGGL((k_pack<float, double>), dim3(gp), dim3(kBlock), 0, stream, nsend, P.d_send_idx, vec, m.d_sendbuf);
     hipError_t e = exchange_packed(c, P, m.d_recvbuf, stream);
     if (e != hipSuccess) return e;
     if (nrecv > 0) {
@@ -297,6 +310,79 @@ hipError_t allreduce_buffer(Ctx* c, const double* src, double* dst, size_t n) {
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return e;
     if (m.cb_allreduce(m.cb_user, m.h_red, (int64_t)n) != 0) return hipErrorUnknown;
     return hipMemcpyAsync(dst, m.h_red, n * sizeof(double), hipMemcpyHostToDevice, c->stream);
+}
+
+// In-place all-gather of blocks of bytes: rank r's block [off[r], off[r+1]) of `buf` (device memory; this rank's own
+// block is valid on entry) becomes valid on every rank.  RCCL: ncclAllGather when the blocks are equal, else grouped
+// ncclSend / ncclRecv between all pairs.  Host-staged: through the EXCHANGE callback with every other rank as a
+// neighbour (the block travels as doubles, padded to 8 bytes), so any transport written against the two callbacks of
+// shk_comm_init_callbacks serves it.  Replaces the all-reduces of zero-padded vectors of rounds 1-2: 1/P of the bytes
+// (and float instead of double for the replicated level's right-hand side and operator values).
+hipError_t allgather_blocks(Ctx* c, void* buf, const std::vector<int64_t>& off) {
+    Comm& m = c->comm;
+    if (m.kind == Comm::NONE || m.nranks <= 1) return hipSuccess;
+    PhaseTimer t(c, SHK_PH_HALO);
+    const int R = m.nranks, me = m.rank;
+    const int64_t mine = off[me + 1] - off[me];
+    m.n_allgather += 1;
+    m.bytes_allgather += off[R] - mine;
+    if (m.timing_only) return hipSuccess;
+    char* b = reinterpret_cast<char*>(buf);
+    if (m.kind == Comm::RCCL) {
+        ncclComm_t comm = reinterpret_cast<ncclComm_t>(m.nccl);
+        bool equal = true;
+        for (int r = 0; r < R; ++r) equal = equal && off[r + 1] - off[r] == mine;
+        ncclResult_t res = ncclSuccess;
+        if (equal) {
+            res = g_rccl.AllGather(b + off[me], b, (size_t)mine, ncclChar, comm, c->stream);
+        } else {
+            g_rccl.GroupStart();
+            for (int r = 0; r < R; ++r) {
+                if (r == me) continue;
+                if (mine > 0) g_rccl.Send(b + off[me], (size_t)mine, ncclChar, r, comm, c->stream);
+                if (off[r + 1] > off[r]) g_rccl.Recv(b + off[r], (size_t)(off[r + 1] - off[r]), ncclChar, r, comm, c->stream);
+            }
+            res = g_rccl.GroupEnd();
+        }
+        return res == ncclSuccess ? hipSuccess : hipErrorUnknown;
+    }
+    // host-staged: my block, padded to doubles, goes to every other rank through the exchange callback
+    auto nd = [&](int r) { return (off[r + 1] - off[r] + 7) / 8; };   // doubles of rank r's block
+    std::vector<int32_t> nb;
+    std::vector<int64_t> sp(1, 0), rp(1, 0);
+    for (int r = 0; r < R; ++r) {
+        if (r == me) continue;
+        nb.push_back(r);
+        sp.push_back(sp.back() + nd(me));
+        rp.push_back(rp.back() + nd(r));
+    }
+    const size_t need = (size_t)std::max<int64_t>(sp.back() + rp.back(), 1);
+    if (need > m.h_red_cap) {
+        if (m.h_red) (void)hipHostFree(m.h_red);
+        m.h_red = nullptr;
+        hipError_t e = hipHostMalloc((void**)&m.h_red, need * sizeof(double));
+        if (e != hipSuccess) return e;
+        m.h_red_cap = need;
+    }
+    double* hs = m.h_red;
+    double* hr = m.h_red + sp.back();
+    hipError_t e = hipSuccess;
+    if (mine > 0) {
+        hs[nd(me) - 1] = 0.0;   // padding bytes of the last double
+        e = hipMemcpyAsync(hs, b + off[me], (size_t)mine, hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return e;
+    for (size_t k = 1; k < nb.size(); ++k) std::memcpy(hs + sp[k], hs, (size_t)nd(me) * sizeof(double));
+    if (m.cb_exchange(m.cb_user, (int32_t)nb.size(), nb.data(), hs, sp.data(), hr, rp.data()) != 0) return hipErrorUnknown;
+    for (size_t k = 0; k < nb.size(); ++k) {
+        const int r = nb[k];
+        if (off[r + 1] > off[r] &&
+            (e = hipMemcpyAsync(b + off[r], hr + rp[k], (size_t)(off[r + 1] - off[r]), hipMemcpyHostToDevice, c->stream)) != hipSuccess)
+            return e;
+    }
+    // the pinned staging buffer is reused by the next call: the copies above must have left it
+    return hipStreamSynchronize(c->stream);
 }
 
 // One workgroup per reduction slot: this subdomain's partial array summed in a fixed order (then, when the products

@@ -331,6 +331,9 @@ struct AmgXfer {  // level l -> l+1
     uint16_t* ap_col16 = nullptr;
     uint8_t* ap_rowlen = nullptr;
     float* ap_vals = nullptr;
+    // decomposed levels: coarse column of each ghost column of the fine level (frozen-ghost smoothing, AmgHierarchy)
+    int32_t* ghost_col = nullptr;
+    int32_t n_ghost = 0;
 };
 // A hierarchy is either block-local (the owned diagonal block of a subdomain, or the whole matrix of a single
 // context: no communication) or distributed (ghost columns kept on every level, per-level halo plans, one
@@ -389,8 +392,23 @@ struct AmgHierarchy {
     // exchange below it, and no loss of couplings.  The arrays below belong to the distributed hierarchy ...
     AmgHierarchy* rep = nullptr;
     int32_t rep_row0 = 0, rep_n = 0;          // my rows [rep_row0, rep_row0 + n) of the rep_n global rows
-    float *rep_rloc = nullptr, *rep_xglob = nullptr;
-    double *rep_rglob = nullptr, *rep_gtmp = nullptr;   // gathered right-hand side; gathered operator values
+    float *rep_rglob = nullptr, *rep_xglob = nullptr;   // gathered right-hand side (my block is written in place by the
+                                              // restriction, the others arrive by ONE in-place all-gather of floats per
+                                              // cycle: 1 / (2 P) of the bytes of rounds 1-2's zero-padded double all-reduce)
+    std::vector<int64_t> rep_rhs_off, rep_val_off;   // byte offsets of every subdomain's block of rep_rglob / of the
+                                              // global level's SELL values (whole slices: blocks are multiples of 1024 rows)
+    // Frozen-ghost smoothing of the decomposed COARSE levels: inside a level's sweeps a ghost column holds the prolongated
+    // coarse correction alpha * e[coarse column of the ghost] -- known locally once the coarser level's result has been
+    // exchanged for the A*P sweep -- instead of the neighbour's smoothed value.  Still a fixed linear operator; one
+    // exchange per decomposed coarse level and cycle instead of two, and all sweeps of such a level can run inside one
+    // launch.  Measured on the 8-way split of the 10M-DOF mesh (Krylov iterations of the first four steps | ghost
+    // exchanges per Krylov iteration; tools/sweep_ghost_mask.sh, profiles/r03_ghost_policy_sweep.md): every level
+    // exchanging after its first sweep (rounds 1-2) 397 | 13.7; every level frozen 520 | 6.9; only the finest level
+    // exchanging 394 | 9.2 -- the default; additionally dropping the exchange of a frozen level's result 422-439 | 6.9
+    // and 797 | 4.6 (no gain at 10-30 us per round).  SHK_AMG_GHOST_EXCHANGE = bit mask of the levels that exchange
+    // after their first sweep (default 1); SHK_AMG_E_EXCHANGE = mask of the frozen levels whose result is exchanged.
+    uint32_t frozen_mask = ~1u;   // bit l: level l runs with frozen ghosts
+    uint32_t e_exchange_mask = ~0u;   // bit l: level l's final result is exchanged for the finer level's A*P sweep
     // ... and these to `rep` itself: its own top operator (global level), values refreshed by the owner hierarchy
     int32_t *t_ptr = nullptr, *t_col = nullptr, *t_cbase = nullptr, *t_ptr16 = nullptr, *t_diag = nullptr;
     uint16_t* t_col16 = nullptr;
@@ -424,6 +442,7 @@ struct Comm {
     std::vector<HaloPlan> plans;             // [0] fine level, [l] multigrid level l (distributed hierarchy)
     int64_t n_exchange = 0, n_allreduce = 0, bytes_exchange = 0, bytes_allreduce = 0;   // message rounds since creation
     int64_t n_overlapped = 0;                // of n_exchange: issued on comm_stream behind an interior pass
+    int64_t n_allgather = 0, bytes_allgather = 0;   // in-place all-gathers (replicated level: right-hand side, operator values)
     bool timing_only = false;                // shk_comm_set_timing_only: messages are skipped (results wrong, durations right)
     double* d_sendbuf = nullptr;             // sized for plans[0], the largest
     double* d_recvbuf = nullptr;             // staging of a float vector's ghosts (they travel as doubles)
@@ -583,6 +602,7 @@ hipError_t halo_begin(Ctx* c, double* vec);
 hipError_t halo_begin_f32(Ctx* c, float* vec);
 hipError_t halo_end(Ctx* c);
 hipError_t allreduce_buffer(Ctx* c, const double* src, double* dst, size_t n);  // element-wise sum over subdomains
+hipError_t allgather_blocks(Ctx* c, void* buf, const std::vector<int64_t>& off);   // in place; off = R + 1 byte offsets
 int amg_setup_distributed(Ctx* c, std::string& err);  // collective
 hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense, bool decided = false, bool top_only = false);
 hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout);

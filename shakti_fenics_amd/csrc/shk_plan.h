@@ -72,6 +72,10 @@ struct AmgLevelPlan {
     std::vector<int32_t> ap_gptr;   // AP slots+1 into ap_glist
     std::vector<int32_t> ap_glist;  // fine slots summed into each AP slot, ascending
     bool with_ap = false;
+    // decomposed levels: the coarse COLUMN (own aggregate, ghost aggregate, or global row of the replicated level) of
+    // each ghost column of the fine level -- a ghost's value inside the fine level's sweeps is the prolongated coarse
+    // correction alpha * e[ghost_col[g]] (filled by amg_setup_distributed)
+    std::vector<int32_t> ghost_col;
 };
 
 struct HostPlan {

@@ -1,12 +1,14 @@
 // Experiment switches of the library: every SHK_* environment variable it honours is read HERE, once per process,
-// into one struct; `overrides` lists the ones that were set ("NAME=value, ..."), which shk_env_overrides() reports and
-// the Python mirror's md.solve() logs -- a stray variable can no longer change a run unnoticed.  Defaults are what
+// into one struct; overrides() lists the ones that are set ("NAME=value, ..."), which shk_env_overrides() reports and
+// the Python mirror's md.solve() logs -- a stray variable can no longer change a run unnoticed.  After that first read
+// the set only changes through the explicit call shk_tunable_set (tests, probes), which is recorded the same way.  Defaults are what
 // every committed measurement was taken with; none of these switches can change WHAT is computed (only block shapes,
 // placements, schedules and the preconditioner's tuning).  The assembly kernel's timing ablations, which do produce
 // wrong results by construction, exist only in builds compiled with -DSHK_EXPERIMENTS (`make probe`).
 #pragma once
 #include <cstdint>
 #include <cstdlib>
+#include <map>
 #include <string>
 
 namespace shk {
@@ -35,8 +37,10 @@ struct Tunables {
     double amg_w1 = 0.0, amg_w2 = 0.0;   // SHK_AMG_W1 / W2  absolute dampings of the two finest-level sweeps
     int amg_halo_levels = -1;     // SHK_AMG_HALO_LEVELS  decomposed levels whose sweeps see their neighbours (-1 = all)
     int64_t amg_rep_rows = -1;    // SHK_AMG_REP_ROWS global size from which the coarse levels are replicated (-1 = default)
-    int amg_ghost_exchange = -1;  // SHK_AMG_GHOST_EXCHANGE  1: exchange ghosts after the first sweep of a decomposed level
-                                  //                  (rounds 1-2); 0: ghosts hold the prolongated coarse correction (default)
+    int amg_ghost_exchange = -1;  // SHK_AMG_GHOST_EXCHANGE  bit mask of the decomposed levels that exchange ghosts after their
+                                  //                  first sweep (-1 = default 1: the finest level only; 7 = rounds 1-2)
+    int amg_e_exchange = -1;      // SHK_AMG_E_EXCHANGE  bit mask of frozen levels whose result is still exchanged for the finer
+                                  //                  level's A*P sweep (-1 = all)
     int gal_ilp[2] = {1, 4}, gal_grid[2] = {1024, 2048}, gal_contig[2] = {1, 0};   // SHK_GAL_ILP0/1, _GRID0/1, _CONTIG0/1
     bool gj_pivotwise = false;    // SHK_GJ_PIVOTWISE round 1's dense inverse (cross-checks)
     // Krylov driver
@@ -49,52 +53,109 @@ struct Tunables {
     int overlap = -1;             // SHK_OVERLAP      interior / boundary overlap of the finest level's exchanges (-1 = default off)
     bool debug = false;           // SHK_DEBUG        print the smoother's spectral estimates and damping caps
     int asm_ablate = 0;           // SHK_ASM_ABLATE   honoured by -DSHK_EXPERIMENTS builds only
-    std::string overrides;        // "NAME=value, ..." of every variable above that is set in the environment
-    int n_overrides = 0;
+    // every switch that is set: by the environment at first use, or by shk_tunable_set since ("NAME=value, ...")
+    std::map<std::string, std::string> set;
+    std::string overrides() const {
+        std::string o;
+        for (const auto& kv : set) o += (o.empty() ? "" : ", ") + kv.first + "=" + kv.second;
+#ifdef SHK_EXPERIMENTS
+        o += std::string(o.empty() ? "" : ", ") + "[probe build: -DSHK_EXPERIMENTS]";
+#endif
+        return o;
+    }
 };
 
-inline const Tunables& tunables() {
-    static const Tunables T = [] {
-        Tunables t;
-        auto raw = [&](const char* name) -> const char* {
-            const char* s = std::getenv(name);
-            if (s) {
-                if (!t.overrides.empty()) t.overrides += ", ";
-                t.overrides += std::string(name) + "=" + s;
-                ++t.n_overrides;
-            }
-            return s;
-        };
-        auto geti = [&](const char* name, int& v) { if (const char* s = raw(name)) v = std::atoi(s); };
-        auto getl = [&](const char* name, int64_t& v) { if (const char* s = raw(name)) v = std::atoll(s); };
-        auto getd = [&](const char* name, double& v) { if (const char* s = raw(name)) v = std::atof(s); };
-        auto getb = [&](const char* name, bool& v) { if (const char* s = raw(name)) v = std::atoi(s) != 0; };
-        geti("SHK_ASM_SLICES", t.asm_slices); geti("SHK_ASM_CELLS", t.asm_cells); geti("SHK_SORT_WINDOW", t.sort_window);
-        getb("SHK_REORDER", t.reorder); geti("SHK_XCD", t.xcd);
-        getb("SHK_AMG", t.amg); geti("SHK_AMG_COARSEST", t.amg_coarsest); getd("SHK_AMG_ALPHA", t.amg_alpha);
-        geti("SHK_AMG_COARSE4", t.amg_coarse4); geti("SHK_AMG_COARSE4_FROM", t.amg_coarse4_from);
-        geti("SHK_AMG_DENSE_PERIOD", t.amg_dense_period); getl("SHK_AMG_W_ROWS", t.amg_w_rows);
-        getd("SHK_AMG_DAMP_SCALE", t.amg_damp_scale); geti("SHK_AMG_LANCZOS", t.amg_lanczos); getb("SHK_AMG_REUSE", t.amg_reuse);
-        geti("SHK_AMG_LAMBDA_PERIOD", t.amg_lambda_period); getb("SHK_FUSED_RESTRICT", t.fused_restrict);
-        getb("SHK_AMG_FUSED_SWEEPS", t.amg_fused_sweeps);
-        getd("SHK_AMG_W1", t.amg_w1); getd("SHK_AMG_W2", t.amg_w2); geti("SHK_AMG_HALO_LEVELS", t.amg_halo_levels);
-        getl("SHK_AMG_REP_ROWS", t.amg_rep_rows); geti("SHK_AMG_GHOST_EXCHANGE", t.amg_ghost_exchange);
-        geti("SHK_GAL_ILP0", t.gal_ilp[0]); geti("SHK_GAL_ILP1", t.gal_ilp[1]);
-        geti("SHK_GAL_GRID0", t.gal_grid[0]); geti("SHK_GAL_GRID1", t.gal_grid[1]);
-        geti("SHK_GAL_CONTIG0", t.gal_contig[0]); geti("SHK_GAL_CONTIG1", t.gal_contig[1]);
-        getb("SHK_GJ_PIVOTWISE", t.gj_pivotwise);
-        geti("SHK_WARM_ITS", t.warm_its); geti("SHK_KRYLOV_CHUNK", t.krylov_chunk); getd("SHK_KRYLOV_NEAR", t.krylov_near);
-        geti("SHK_PREDICT_LAST", t.predict_last);
-        getd("SHK_COMM_TIMEOUT_S", t.comm_timeout_s); geti("SHK_OVERLAP", t.overlap); getb("SHK_DEBUG", t.debug);
+// name -> field.  Returns false for a name the library does not honour.
+inline bool tunable_apply(Tunables& t, const std::string& name, const char* s) {
+    auto I = [&](int& v) { v = std::atoi(s); return true; };
+    auto L = [&](int64_t& v) { v = std::atoll(s); return true; };
+    auto D = [&](double& v) { v = std::atof(s); return true; };
+    auto B = [&](bool& v) { v = std::atoi(s) != 0; return true; };
+    if (name == "SHK_ASM_SLICES") return I(t.asm_slices);
+    if (name == "SHK_ASM_CELLS") return I(t.asm_cells);
+    if (name == "SHK_SORT_WINDOW") return I(t.sort_window);
+    if (name == "SHK_REORDER") return B(t.reorder);
+    if (name == "SHK_XCD") return I(t.xcd);
+    if (name == "SHK_AMG") return B(t.amg);
+    if (name == "SHK_AMG_COARSEST") return I(t.amg_coarsest);
+    if (name == "SHK_AMG_ALPHA") return D(t.amg_alpha);
+    if (name == "SHK_AMG_COARSE4") return I(t.amg_coarse4);
+    if (name == "SHK_AMG_COARSE4_FROM") return I(t.amg_coarse4_from);
+    if (name == "SHK_AMG_DENSE_PERIOD") return I(t.amg_dense_period);
+    if (name == "SHK_AMG_W_ROWS") return L(t.amg_w_rows);
+    if (name == "SHK_AMG_DAMP_SCALE") return D(t.amg_damp_scale);
+    if (name == "SHK_AMG_LANCZOS") return I(t.amg_lanczos);
+    if (name == "SHK_AMG_REUSE") return B(t.amg_reuse);
+    if (name == "SHK_AMG_LAMBDA_PERIOD") { I(t.amg_lambda_period); if (t.amg_lambda_period < 1) t.amg_lambda_period = 1; return true; }
+    if (name == "SHK_FUSED_RESTRICT") return B(t.fused_restrict);
+    if (name == "SHK_AMG_FUSED_SWEEPS") return B(t.amg_fused_sweeps);
+    if (name == "SHK_AMG_W1") return D(t.amg_w1);
+    if (name == "SHK_AMG_W2") return D(t.amg_w2);
+    if (name == "SHK_AMG_HALO_LEVELS") return I(t.amg_halo_levels);
+    if (name == "SHK_AMG_REP_ROWS") return L(t.amg_rep_rows);
+    if (name == "SHK_AMG_GHOST_EXCHANGE") return I(t.amg_ghost_exchange);
+    if (name == "SHK_AMG_E_EXCHANGE") return I(t.amg_e_exchange);
+    if (name == "SHK_GAL_ILP0") return I(t.gal_ilp[0]);
+    if (name == "SHK_GAL_ILP1") return I(t.gal_ilp[1]);
+    if (name == "SHK_GAL_GRID0") return I(t.gal_grid[0]);
+    if (name == "SHK_GAL_GRID1") return I(t.gal_grid[1]);
+    if (name == "SHK_GAL_CONTIG0") return I(t.gal_contig[0]);
+    if (name == "SHK_GAL_CONTIG1") return I(t.gal_contig[1]);
+    if (name == "SHK_GJ_PIVOTWISE") return B(t.gj_pivotwise);
+    if (name == "SHK_WARM_ITS") { I(t.warm_its); if (t.warm_its < 1) t.warm_its = 1; return true; }
+    if (name == "SHK_KRYLOV_CHUNK") return I(t.krylov_chunk);
+    if (name == "SHK_KRYLOV_NEAR") return D(t.krylov_near);
+    if (name == "SHK_PREDICT_LAST") return I(t.predict_last);
+    if (name == "SHK_COMM_TIMEOUT_S") return D(t.comm_timeout_s);
+    if (name == "SHK_OVERLAP") return I(t.overlap);
+    if (name == "SHK_DEBUG") return B(t.debug);
 #ifdef SHK_EXPERIMENTS
-        geti("SHK_ASM_ABLATE", t.asm_ablate);
-        t.overrides += std::string(t.overrides.empty() ? "" : ", ") + "[probe build: -DSHK_EXPERIMENTS]";
+    if (name == "SHK_ASM_ABLATE") return I(t.asm_ablate);
 #endif
-        if (t.amg_lambda_period < 1) t.amg_lambda_period = 1;
-        if (t.warm_its < 1) t.warm_its = 1;
+    return false;
+}
+
+inline const char* const* tunable_names(int* n) {
+    static const char* const names[] = {
+        "SHK_ASM_SLICES", "SHK_ASM_CELLS", "SHK_SORT_WINDOW", "SHK_REORDER", "SHK_XCD", "SHK_AMG", "SHK_AMG_COARSEST",
+        "SHK_AMG_ALPHA", "SHK_AMG_COARSE4", "SHK_AMG_COARSE4_FROM", "SHK_AMG_DENSE_PERIOD", "SHK_AMG_W_ROWS",
+        "SHK_AMG_DAMP_SCALE", "SHK_AMG_LANCZOS", "SHK_AMG_REUSE", "SHK_AMG_LAMBDA_PERIOD", "SHK_FUSED_RESTRICT",
+        "SHK_AMG_FUSED_SWEEPS", "SHK_AMG_W1", "SHK_AMG_W2", "SHK_AMG_HALO_LEVELS", "SHK_AMG_REP_ROWS",
+        "SHK_AMG_GHOST_EXCHANGE", "SHK_AMG_E_EXCHANGE", "SHK_GAL_ILP0", "SHK_GAL_ILP1", "SHK_GAL_GRID0", "SHK_GAL_GRID1", "SHK_GAL_CONTIG0",
+        "SHK_GAL_CONTIG1", "SHK_GJ_PIVOTWISE", "SHK_WARM_ITS", "SHK_KRYLOV_CHUNK", "SHK_KRYLOV_NEAR", "SHK_PREDICT_LAST",
+        "SHK_COMM_TIMEOUT_S", "SHK_OVERLAP", "SHK_DEBUG", "SHK_ASM_ABLATE"};
+    *n = (int)(sizeof(names) / sizeof(names[0]));
+    return names;
+}
+
+// The process-wide set: initialised from the environment at first use, changed afterwards only through
+// shk_tunable_set (tests and probes: an explicit call, recorded like an environment override).
+inline Tunables& tunables_mut() {
+    static Tunables T = [] {
+        Tunables t;
+        int n = 0;
+        const char* const* names = tunable_names(&n);
+        for (int i = 0; i < n; ++i)
+            if (const char* s = std::getenv(names[i]))
+                if (tunable_apply(t, names[i], s)) t.set[names[i]] = s;
         return t;
     }();
     return T;
+}
+inline const Tunables& tunables() { return tunables_mut(); }
+
+// value == nullptr: back to the default.  Returns false for an unknown name.
+inline bool tunable_set(const std::string& name, const char* value) {
+    Tunables& T = tunables_mut();
+    Tunables probe;
+    if (!tunable_apply(probe, name, value ? value : "0")) return false;
+    std::map<std::string, std::string> keep = T.set;
+    if (value) keep[name] = value; else keep.erase(name);
+    Tunables fresh;
+    for (const auto& kv : keep) tunable_apply(fresh, kv.first, kv.second.c_str());
+    fresh.set = keep;
+    T = fresh;
+    return true;
 }
 
 }  // namespace shk

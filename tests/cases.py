@@ -55,3 +55,23 @@ def c1_case():
                  inputs=sf["inputs"])
     bc = O.boundary_dofs(dom.xy, dom.cells, outflow_predicate(dom))
     return dom, f, bc, N_BDRY
+
+
+def conical_rule(n: int = 4) -> np.ndarray:
+    """(n*n, 3) rows x, y, w of the conical (collapsed-square) Gauss-Jacobi x Gauss-Legendre product rule on the
+    reference triangle: exact to total degree 2n - 1 (n = 4: 16 points, degree 7, weights sum to 1/2).  A DIFFERENT
+    exact degree-7 rule than the symmetric 15-point one the build ships: injected through shk_set_quadrature and the
+    oracle's `quad` argument, it measures how far the results can move with the point set (tests/test_gpu_sensitivity.py).
+        int_T f = int_0^1 int_0^1 f(u, v (1 - u)) (1 - u) dv du"""
+    from scipy.special import roots_jacobi, roots_legendre
+    xu, wu = roots_jacobi(n, 1.0, 0.0)       # weight (1 - x) on [-1, 1]
+    xv, wv = roots_legendre(n)
+    u, wu = 0.5 * (1.0 + xu), 0.25 * wu      # (1 - u) du = (1 - x) dx / 4
+    v, wv = 0.5 * (1.0 + xv), 0.5 * wv
+    pts = [(ui, vj * (1.0 - ui), wi * wj) for ui, wi in zip(u, wu) for vj, wj in zip(v, wv)]
+    return np.array(pts)
+
+
+def moulin_case_62k(moulins: int = 20):
+    """The 62k-DOF mesh with lake storage and moulins (1 + omega Re active): the largest size the LU oracle steps in seconds."""
+    return make_case(nx=351, ny=177, Lx=50e3, Ly=25e3, storage_on=True, moulins=moulins)

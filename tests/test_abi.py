@@ -57,3 +57,26 @@ def test_no_gpu_means_a_loud_error_not_a_fallback(lib, gpu_available):
     cells = np.array([[0, 1, 2]], dtype=np.int32)
     with pytest.raises(lib.ShaktiHipError):
         lib.ShaktiHip(xy, cells)
+
+
+def test_experiment_switches_are_read_once_and_reported(lib):
+    """csrc/shk_tunables.h: SHK_* variables are read into one struct at first use and listed by shk_env_overrides;
+    afterwards only the explicit setter changes them (and is listed the same way); unknown names are refused."""
+    import subprocess
+    import sys
+    code = ("import os; os.environ['SHK_AMG_ALPHA'] = '1.7'; os.environ['SHK_NOT_A_SWITCH'] = '1';"
+            "from shakti_fenics_amd import _lib;"
+            "a = _lib.env_overrides(); os.environ['SHK_AMG_W1'] = '0.9'; b = _lib.env_overrides();"
+            "ctx = _lib.tunables(SHK_GJ_PIVOTWISE=1, SHK_AMG_ALPHA=1.2); ctx.__enter__(); c = _lib.env_overrides(); ctx.__exit__();"
+            "d = _lib.env_overrides(); print('|'.join((a, b, c, d)))")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a, b, c, d = r.stdout.strip().split("|")
+    assert a == "SHK_AMG_ALPHA=1.7"                     # the unknown variable is not a switch
+    assert b == a                                       # a later change of the environment is NOT picked up
+    assert c == "SHK_AMG_ALPHA=1.2, SHK_GJ_PIVOTWISE=1"
+    assert d == a                                       # back to what the environment said
+    assert lib.env_overrides() == ""                    # this process runs on the defaults
+    L = lib.load()
+    assert L.shk_tunable_set(b"SHK_NOPE", b"1") != 0 and b"unknown experiment switch" in L.shk_last_error()
+    assert L.shk_tunable_set(b"SHK_ASM_ABLATE", b"1") != 0   # assembly ablations exist in probe builds only

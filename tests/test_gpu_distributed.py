@@ -20,8 +20,9 @@ def _launch(nproc, transport, port, extra=(), env_extra=None):
     # The library's DEFAULT schedule (serialised exchanges, interior / boundary overlap off) is what the first real
     # multi-GPU run takes, so it is what every decomposition below runs; the overlapped schedule (SHK_OVERLAP=1) is an
     # extra parametrisation of the tests that name it.
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
-    env.pop("SHK_OVERLAP", None) if not (env_extra and "SHK_OVERLAP" in env_extra) else None
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("SHK_OVERLAP", None)
+    env.update(env_extra or {})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"),
            "--transport", transport, *extra]

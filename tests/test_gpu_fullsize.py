@@ -22,15 +22,12 @@ DT = 3600.0
 
 @pytest.fixture(scope="module", params=["c2_1m", "c4_10m"])
 def big(request):
-    import os
+    from shakti_fenics_amd import _lib
     from shakti_fenics_amd.runner import SingleRunner
     # rebuild the multigrid's dense coarsest inverse at every time step, so that the preconditioner (and with it
     # every bit of the result) depends on the state alone, not on how many solves the context has seen
-    os.environ["SHK_AMG_DENSE_PERIOD"] = "1"
-    try:
+    with _lib.tunables(SHK_AMG_DENSE_PERIOD=1):
         r = SingleRunner(request.param, storage=True, moulins=20)
-    finally:
-        del os.environ["SHK_AMG_DENSE_PERIOD"]
     r.step(0)   # leave the trivial initial state: q, melt_n, b have evolved, N != N_bdry
     yield r
     r.close()

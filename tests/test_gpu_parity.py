@@ -259,8 +259,7 @@ def test_blocked_dense_inverse_equals_the_pivotwise_one(hip):
     bc = O.boundary_dofs(dom.xy, dom.cells, outflow_predicate(dom))
     out = {}
     for mode in ("0", "1"):
-        os.environ["SHK_GJ_PIVOTWISE"] = mode
-        try:
+        with hip.tunables(SHK_GJ_PIVOTWISE=mode):
             ctx = hip.ShaktiHip(dom.xy, dom.cells)
             ctx.set_params(precond=hip.PRECOND["amg"])
             upload(ctx, f, bc, N_BDRY)
@@ -270,8 +269,6 @@ def test_blocked_dense_inverse_equals_the_pivotwise_one(hip):
             assert conv
             out[mode] = (its, ctx.get_field("dx"))
             ctx.close()
-        finally:
-            del os.environ["SHK_GJ_PIVOTWISE"]
     assert abs(out["0"][0] - out["1"][0]) <= 1, (out["0"][0], out["1"][0])
     assert rel_l2(out["0"][1], out["1"][1]) < 1e-8
 

@@ -122,12 +122,8 @@ def test_multigrid_dampings_are_not_on_a_cliff(hip, mesh):
     for tag, env in (("nominal", {}), ("damp-20%", {"SHK_AMG_DAMP_SCALE": "0.8"}), ("damp+20%", {"SHK_AMG_DAMP_SCALE": "1.2"}),
                      ("alpha-20%", {"SHK_AMG_ALPHA": "1.2"}), ("alpha+20%", {"SHK_AMG_ALPHA": "1.8"}),
                      ("all+20%", {"SHK_AMG_DAMP_SCALE": "1.2", "SHK_AMG_ALPHA": "1.8"})):
-        os.environ.update(env)
-        try:
+        with hip.tunables(**env):   # the hierarchy reads the switches when the context is created
             ctx = hip.ShaktiHip(dom.xy, dom.cells)
-        finally:
-            for k in env:
-                del os.environ[k]
         ctx.set_params(precond=hip.PRECOND["amg"])
         upload(ctx, f, bc, g)
         total = 0

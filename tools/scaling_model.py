@@ -146,7 +146,7 @@ def main():
     prof, wall, kk = timed_newton(ctx, a.dt, a.k)
     one = per_iteration(prof, a.k)
     one.update(wall_ms=1e3 * wall, asm_ms=prof["assemble"]["ms"] / max(prof["assemble"]["launches"], 1),
-               other_ms=prof["other"]["ms"], krylov_its=kk, steps=hist, rounds=0.0, allreduces=0.0)
+               other_ms=prof["other"]["ms"], krylov_its=kk, steps=hist, rounds=0.0, allreduces=0.0, allgathers=0.0)
     ctx.profile_enable(True); ctx.profile_read(reset=True)
     ctx.update_explicit(a.dt)
     one["update_ms"] = ctx.profile_read(reset=True)["update"]["ms"]
@@ -209,6 +209,8 @@ def main():
         run.update(wall_ms=1e3 * wall, asm_ms=prof["assemble"]["ms"] / max(prof["assemble"]["launches"], 1),
                    other_ms=prof["other"]["ms"], krylov_its=kk, steps=steps[0],
                    rounds=(s1["exchanges"] - s0["exchanges"]) / nk, allreduces=(s1["allreduces"] - s0["allreduces"]) / nk,
+                   allgathers=(s1["allgathers"] - s0["allgathers"]) / nk,
+                   bytes_allgathered=(s1["bytes_allgathered"] - s0["bytes_allgathered"]) / nk,
                    bytes_exchanged=(s1["bytes_exchanged"] - s0["bytes_exchanged"]) / nk,
                    bytes_allreduced=(s1["bytes_allreduced"] - s0["bytes_allreduced"]) / nk,
                    real_rounds_per_it={k: v / max(kr, 1) for k, v in stats_warm[0].items()},
@@ -220,7 +222,7 @@ def main():
         c0.profile_enable(False)
         res["runs"][str(P)] = run
         say(f"P={P}: rank 0 alone: {run['kernel_ms']:.3f} ms of kernels per Krylov iteration, {run['rounds']:.1f} exchanges + "
-            f"{run['allreduces']:.1f} all-reduces per iteration")
+            f"{run['allreduces']:.1f} all-reduces + {run['allgathers']:.1f} all-gathers per iteration")
         for c in ctxs:
             c.close()
         del ctxs, subs
@@ -235,7 +237,7 @@ def main():
     def t_it(run, m_us):   # ms per Krylov iteration
         newton_over = 2 * run["asm_ms"] + run["other_ms"]
         wall_it = (run["wall_ms"] - newton_over) / a.k
-        return max(wall_it, run["kernel_ms"]) + (run["rounds"] + run["allreduces"]) * m_us * 1e-3
+        return max(wall_it, run["kernel_ms"]) + (run["rounds"] + run["allreduces"] + run["allgathers"]) * m_us * 1e-3
 
     def t_step(run, m_us):
         return (n_newton + 1) * run["asm_ms"] + n_newton * run["other_ms"] + K * t_it(run, m_us) + run["update_ms"]
@@ -264,8 +266,8 @@ def report(res, a):
          f"results wrong, durations right; one Newton iteration with exactly {res['k_fixed']} Krylov iterations after {res['warm_steps']} real steps of all P",
          "subdomains); the cost of a message round is the model's free parameter.  `tools/scaling_model.py`.", "",
          "## Measured: ms per Krylov iteration on rank 0's subdomain (hipEvent kernel time per phase)", "",
-         "| P | owned rows | fine level (smoother 2 + first sweep 2) | Krylov products | vector kernels | decomposed coarse levels | replicated levels | restrict + dense + other | pack / unpack | kernels total | wall per iteration | launches | exchanges | all-reduces |",
-         "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+         "| P | owned rows | fine level (smoother 2 + first sweep 2) | Krylov products | vector kernels | decomposed coarse levels | replicated levels | restrict + dense + other | pack / unpack | kernels total | wall per iteration | launches | exchanges | all-reduces | all-gathers |",
+         "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
     for P in Ps:
         r = runs[P]
         dec = sum(r[f"amg_l{l}"] for l in range(1, 9))
@@ -274,7 +276,7 @@ def report(res, a):
         wall_it = (r["wall_ms"] - newton_over) / res["k_fixed"]
         L.append(f"| {P} | {r.get('n_own', res['dofs'])} | {r['amg_fine'] + r['amg_first']:.3f} | {r['spmv']:.3f} | {r['vector']:.3f} | {dec:.3f} | "
                  f"{r['amg_rep']:.3f} | {rest:.3f} | {r['halo']:.3f} | {r['kernel_ms']:.3f} | {wall_it:.3f} | {r['launches']:.0f}+coarse | "
-                 f"{r['rounds']:.1f} | {r['allreduces']:.1f} |")
+                 f"{r['rounds']:.1f} | {r['allreduces']:.1f} | {r['allgathers']:.1f} |")
     L += ["", "Per-level sweeps of the decomposed hierarchy (ms per Krylov iteration = two cycles):", "",
           "| P | " + " | ".join(f"level {l}" for l in range(1, 9)) + " | restrictions | dense solve | replicated hierarchy |", "|---|" + "---|" * 11]
     for P in Ps:
@@ -285,7 +287,7 @@ def report(res, a):
         r = runs[P]
         L.append(f"* P = {P}: {r['asm_ms']:.3f} / {r['other_ms']:.3f} / {r['update_ms']:.3f}; real steps before the timed iteration "
                  f"(Newton, Krylov): {r['steps']}" + (f"; message volume per Krylov iteration {r['bytes_exchanged'] / 1e3:.1f} KB exchanged, "
-                                                      f"{r['bytes_allreduced'] / 1e3:.1f} KB all-reduced" if P != '1' else ""))
+                                                      f"{r['bytes_allreduced'] / 1e3:.1f} KB all-reduced, {r['bytes_allgathered'] / 1e3:.1f} KB all-gathered" if P != '1' else ""))
     s = res["step_shape"]
     L += ["", f"## Model: one time step = {s['assemblies']:.0f} assemblies + {s['newton_its']:.0f} Newton iterations + {s['krylov_its']:.1f} Krylov iterations + update", "",
           "| message cost per round | " + " | ".join(f"P = {P}: ms/step (speedup)" for P in Ps) + " |", "|---|" + "---|" * len(Ps)]
