@@ -427,6 +427,133 @@ __global__ __launch_bounds__(kBlock) void k_amg_first(const AmgFirstArgs<TR> a) 
     }
 }
 
+// ---- fused multi-sweep smoother: the four sweeps of a level in ONE launch (SweepPlan, shk_plan.h).
+//   x1 = alpha e[agg] + w0 D^-1 (r - alpha (A P) e)   on S3 = rows within distance 3 of the workgroup's 256-row block
+//   x2 = x1 + w1 D^-1 (r - A x1)                      on S2
+//   x3 = x2 + w2 D^-1 (r - A x2)                      on S1
+//   x4 = x3 + w3 D^-1 (r - A x3)                      on S0 = the block  -> xo
+// A thread owns up to three rows of the extended block -- row tid of the block itself, local rows tid + 256 and
+// tid + 512 of the rings -- and keeps what it needs of them in REGISTERS: the matrix rows it recomputes in sweeps 2-4
+// (its own, and the first ring row if that lies in S2), right-hand side and 1/diag.  The kernel is a latency chain
+// on the small levels it exists for, so every global load is issued as early as its address is known: block header
+// (scalar) -> one 16-byte record per ring row -> all row data of the three rows at once -> the gathers of the coarse
+// correction.  Only the iterates pass through LDS (two buffers, ping-pong).  Rows of the block read the level's SELL
+// arrays coalesced; ring rows gather their entries (served by L2: they are the neighbouring blocks' own rows).
+// Ghost columns of a decomposed level (frozen-ghost smoothing) are constants alpha e[ghost_col].
+// Same formulas and slot order as k_amg_first / k_amg_post: the result equals the four separate launches'.
+template <class TR>
+struct AmgSweepArgs {
+    DevSell A;               // the level's operator (ptr used; columns come from the plan)
+    const float* vals;
+    const float* dinv;
+    const TR* r;
+    DevSell AP;              // first sweep: fine rows x coarse columns (ptr, col used)
+    const float* ap_vals;
+    const float* e;          // coarse correction, indexed by the A*P columns
+    const int32_t* agg;
+    int32_t agg_off;
+    const int32_t* ghost_col;   // coarse column of ghost column n_rows + g (nullptr: the level has no ghost columns)
+    int32_t n_ghost;
+    float* xo;               // result: own rows (and, with ghost_col, the ghost segment = the frozen values)
+    float w[4];
+    float alpha;
+    const int* done;
+    int32_t nblk, width;     // plan
+    const int32_t *hdr, *ext_info;
+    const uint16_t *lcol_own, *ring_lcol;
+};
+template <class TR, int W>
+__global__ __launch_bounds__(kSweepRows) void k_amg_sweeps(const AmgSweepArgs<TR> a) {
+    constexpr int WP = kSweepMaxWidthAP;
+    __shared__ float xa[kSweepMaxLocal], xb[kSweepMaxLocal];
+    if (*a.done) return;
+    const int tid = threadIdx.x;
+    const int n = a.A.n_rows;
+    for (int i = blockIdx.x * kSweepRows + tid; i < a.n_ghost; i += gridDim.x * kSweepRows)
+        a.xo[n + i] = a.alpha * a.e[a.ghost_col[i]];
+    for (int b = blockIdx.x; b < a.nblk; b += gridDim.x) {
+        const int r0 = b * kSweepRows, n0 = min(n - r0, kSweepRows);
+        const int32_t* __restrict__ hd = a.hdr + (size_t)8 * b;     // wave-uniform: scalar loads
+        // local row ids: 0 .. n0-1 the block, kSweepRows .. the rings (SweepPlan), then the fixed entries
+        const int ext0 = hd[0], rl0 = hd[1], nS1 = kSweepRows + hd[2], nS2 = nS1 + hd[3], nS3 = nS2 + hd[4], nfix = hd[5];
+        const int4* __restrict__ info = reinterpret_cast<const int4*>(a.ext_info) + ext0;
+        // ---- this thread's rows: local ids t0 = tid (own), t1 = tid + 256, t2 = tid + 512 (rings); row records first
+        const int t1 = tid + kSweepRows, t2 = tid + 2 * kSweepRows;
+        const bool has0 = tid < n0, has1 = t1 < nS3, has2 = t2 < nS3, a1 = t1 < nS2;   // a1: ring row 1 is recomputed later
+        const int4 i1 = has1 ? info[t1 - kSweepRows] : make_int4(0, 0, 0, 0);
+        const int4 i2 = has2 ? info[t2 - kSweepRows] : make_int4(0, 0, 0, 0);
+        const int4 ifx = tid < nfix ? info[nS3 - kSweepRows + tid] : make_int4(n, 0, 0, 0);
+        const int g0 = min(r0 + tid, n - 1), s0 = g0 >> 6;
+        const int base0 = a.A.ptr[s0] + (g0 & 63), wid0 = has0 ? (a.A.ptr[s0 + 1] - a.A.ptr[s0]) >> 6 : 0;
+        const int pbase0 = a.AP.ptr[s0] + (g0 & 63), pwid0 = has0 ? (a.AP.ptr[s0 + 1] - a.AP.ptr[s0]) >> 6 : 0;
+        const int g1 = i1.x, g2 = i2.x;
+        const int len1 = a1 ? (i1.w & 255) : 0, plen1 = has1 ? (i1.w >> 8) : 0, plen2 = has2 ? (i2.w >> 8) : 0;
+        // ---- all row data at once
+        float v0[W], v1[W];
+        uint16_t c0[W], c1[W];
+        const uint16_t* __restrict__ lc1 = a.ring_lcol + (size_t)(rl0 + tid) * a.width;
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            const bool m0 = k < wid0, m1 = k < len1;
+            v0[k] = m0 ? a.vals[base0 + k * kSlice] : 0.0f;
+            c0[k] = m0 ? a.lcol_own[base0 + k * kSlice] : (uint16_t)0;
+            v1[k] = m1 ? a.vals[i1.y + k * kSlice] : 0.0f;
+            c1[k] = m1 ? lc1[k] : (uint16_t)0;
+        }
+        float pv0[WP], pv1[WP], pv2[WP];
+        int32_t pc0[WP], pc1[WP], pc2[WP];
+#pragma unroll
+        for (int k = 0; k < WP; ++k) {
+            const bool m0 = k < pwid0, m1 = k < plen1, m2 = k < plen2;
+            pv0[k] = m0 ? a.ap_vals[pbase0 + k * kSlice] : 0.0f;
+            pc0[k] = m0 ? a.AP.col[pbase0 + k * kSlice] : 0;
+            pv1[k] = m1 ? a.ap_vals[i1.z + k * kSlice] : 0.0f;
+            pc1[k] = m1 ? a.AP.col[i1.z + k * kSlice] : 0;
+            pv2[k] = m2 ? a.ap_vals[i2.z + k * kSlice] : 0.0f;
+            pc2[k] = m2 ? a.AP.col[i2.z + k * kSlice] : 0;
+        }
+        const float rr0 = has0 ? (float)a.r[g0] : 0.0f, rr1 = has1 ? (float)a.r[g1] : 0.0f, rr2 = has2 ? (float)a.r[g2] : 0.0f;
+        const float d0 = has0 ? a.dinv[g0] : 0.0f, d1 = has1 ? a.dinv[g1] : 0.0f, d2 = has2 ? a.dinv[g2] : 0.0f;
+        const int ag0 = has0 ? a.agg[g0] : 0, ag1 = has1 ? a.agg[g1] : 0, ag2 = has2 ? a.agg[g2] : 0;
+        const int gfx = tid < nfix ? a.ghost_col[ifx.x - n] : 0;
+        // ---- gathers of the coarse correction
+        float s0_ = 0.0f, s1_ = 0.0f, s2_ = 0.0f;
+#pragma unroll
+        for (int k = 0; k < WP; ++k) {
+            s0_ += pv0[k] * a.e[pc0[k]];
+            s1_ += pv1[k] * a.e[pc1[k]];
+            s2_ += pv2[k] * a.e[pc2[k]];
+        }
+        const float e0 = a.e[a.agg_off + ag0], e1 = a.e[a.agg_off + ag1], e2 = a.e[a.agg_off + ag2];
+        const float efx = tid < nfix ? a.alpha * a.e[gfx] : 0.0f;
+        __syncthreads();   // the previous block's readers are done with the LDS buffers
+        // ---- sweep 1 on S3 (through A*P), constants of the ghost columns
+        if (has0) xa[tid] = a.alpha * e0 + a.w[0] * d0 * (rr0 - a.alpha * s0_);
+        if (has1) xa[t1] = a.alpha * e1 + a.w[0] * d1 * (rr1 - a.alpha * s1_);
+        if (has2) xa[t2] = a.alpha * e2 + a.w[0] * d2 * (rr2 - a.alpha * s2_);
+        if (tid < nfix) { xa[nS3 + tid] = efx; xb[nS3 + tid] = efx; }
+        __syncthreads();
+        // ---- sweeps 2 .. 4 on S2, S1, S0: from registers and LDS
+        auto row = [&](const float* xin, const float (&v)[W], const uint16_t (&cc)[W]) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int k = 0; k < W; ++k) sum += v[k] * xin[cc[k]];
+            return sum;
+        };
+        {
+            if (has0) xb[tid] = xa[tid] + a.w[1] * d0 * (rr0 - row(xa, v0, c0));
+            if (a1) xb[t1] = xa[t1] + a.w[1] * d1 * (rr1 - row(xa, v1, c1));
+        }
+        __syncthreads();
+        {
+            if (has0) xa[tid] = xb[tid] + a.w[2] * d0 * (rr0 - row(xb, v0, c0));
+            if (t1 < nS1) xa[t1] = xb[t1] + a.w[2] * d1 * (rr1 - row(xb, v1, c1));
+        }
+        __syncthreads();
+        if (has0) a.xo[r0 + tid] = xa[tid] + a.w[3] * d0 * (rr0 - row(xa, v0, c0));
+    }
+}
+
 // ---- tail: every level with <= kTailRows rows runs inside ONE workgroup (restrictions, dense coarsest solve,
 // prolongations and smoothing sweeps separated by workgroup barriers) instead of ~4 tiny launches per level.
 constexpr int kTailRows = 4096;
@@ -989,21 +1116,26 @@ __global__ __launch_bounds__(kBlock) void k_amg_restrict4(int32_t n, const TR* _
     }
 }
 
-// Tables of the four-level restriction for the active hierarchy (nlev = 0: unavailable).
-static RestrictArgs amg_restrict_args(const AmgHierarchy& H) {
-    const bool enabled = tunables().fused_restrict;
+// Tables of the four-level restriction for the active hierarchy (nlev = 0: unavailable).  It starts at the first level
+// `*first` of at most 2^21 rows (a workgroup then has few 256-row groups to walk through, each a memory round trip
+// and four barriers: at 10M rows the finest level's own restriction is faster as a plain launch, and level 2 of 625k
+// rows heads the cascade; at 1M rows the finest level does) and covers up to four transfers, down to `lt`.
+static RestrictArgs amg_restrict_args(const AmgHierarchy& H, size_t lt, size_t* first) {
     RestrictArgs ra{};
-    if (!enabled || H.topA.n_rows > (1 << 21)) return ra;
-    const size_t lt = tail_start(H);
-    for (size_t l = 0; l < lt && l < (size_t)kFusedRestrict; ++l) {
-        const AmgXfer& X = H.xf[l];
+    *first = 0;
+    if (!tunables().fused_restrict) return ra;
+    size_t ls = 0;
+    while (ls < lt && (ls == 0 ? H.topA.n_rows : H.lv[ls].n) > (1 << 21)) ++ls;
+    for (size_t j = 0; j < (size_t)kFusedRestrict && ls + j < lt; ++j) {
+        const AmgXfer& X = H.xf[ls + j];
         if (!X.members_kd || !X.kd_pos) break;
-        ra.members[l] = reinterpret_cast<const int4*>(X.members_kd);
-        ra.pos[l] = X.kd_pos;
-        ra.rc[l] = X.dense ? H.cr : X.onto_global ? H.rep_rglob + H.rep_row0 : H.lv[l + 1].r;
-        ra.nc[l] = X.n_coarse;
-        ra.nlev = (int)l + 1;
+        ra.members[j] = reinterpret_cast<const int4*>(X.members_kd);
+        ra.pos[j] = X.kd_pos;
+        ra.rc[j] = X.dense ? H.cr : X.onto_global ? H.rep_rglob + H.rep_row0 : H.lv[ls + j + 1].r;
+        ra.nc[j] = X.n_coarse;
+        ra.nlev = (int)j + 1;
     }
+    *first = ls;
     return ra;
 }
 
@@ -1036,6 +1168,27 @@ static hipError_t launch_post_split(Ctx* c, const DevSell& A, const float* vals,
     return hipSuccess;
 }
 
+// The four sweeps of one level in one launch (k_amg_sweeps), if the level has a plan.
+template <class TR>
+static bool launch_sweeps(Ctx* c, const DevSweepPlan& S, const DevSell& A, const float* vals, const float* dinv, const TR* r,
+                          const AmgXfer& X, const float* e_cols, int32_t agg_off, bool frozen, float* xo, const float (&w)[4],
+                          float alpha, const int* done) {
+    if (!S.ready()) return false;
+    AmgSweepArgs<TR> a{};
+    a.A = A; a.vals = vals; a.dinv = dinv; a.r = r;
+    a.AP = DevSell{X.n_fine, X.n_coarse_cols, X.ap_nslice, 1, X.ap_ptr, X.ap_col, X.ap_rowlen, X.ap_cbase, X.ap_ptr16, X.ap_col16};
+    a.ap_vals = X.ap_vals; a.e = e_cols; a.agg = X.agg; a.agg_off = agg_off;
+    a.ghost_col = frozen ? X.ghost_col : nullptr; a.n_ghost = frozen ? X.n_ghost : 0;
+    a.xo = xo;
+    for (int k = 0; k < 4; ++k) a.w[k] = w[k];
+    a.alpha = alpha; a.done = done;
+    a.nblk = S.nblk; a.width = S.width; a.hdr = S.hdr; a.ext_info = S.ext_info; a.lcol_own = S.lcol_own; a.ring_lcol = S.ring_lcol;
+    const dim3 g(std::min(S.nblk, 8192));
+    if (S.width <= 12) hipLaunchKernelGGL((k_amg_sweeps<TR, 12>), g, dim3(kSweepRows), 0, c->stream, a);
+    else hipLaunchKernelGGL((k_amg_sweeps<TR, kSweepMaxWidth>), g, dim3(kSweepRows), 0, c->stream, a);
+    return true;
+}
+
 // z = M^-1 r : one V(0,2) cycle.  r and z have the fine level's length; r is not modified.  TR: double for a context's
 // own hierarchies (the Krylov vector), float for the replicated hierarchy (the gathered right-hand side).
 template <class TR>
@@ -1063,13 +1216,19 @@ static hipError_t amg_vcycle_t(Ctx* c, AmgHierarchy& H, const TR* rin, float* zo
     }
     {
         PhaseTimer t(c, ph(SHK_PH_AMG_RESTRICT));
-        const RestrictArgs ra = amg_restrict_args(H);
-        // one launch for four levels while a workgroup has few groups to walk through (each costs a memory round
-        // trip and four barriers); measured at 1M rows: 46.9 -> 45.4 ms/step, at 10M rows the plain cascade wins
-        if (ra.nlev > 1)
-            hipLaunchKernelGGL(k_amg_restrict4<TR>, dim3(std::min((n_top + kBlock - 1) / kBlock, 2048)), dim3(kBlock),
-                               0, c->stream, n_top, rin, ra, done);
-        for (size_t l = ra.nlev > 1 ? (size_t)ra.nlev : 0; l < lt; ++l) {
+        size_t ls = 0;
+        const RestrictArgs ra = amg_restrict_args(H, lt, &ls);
+        // one launch for up to four levels from level `ls` on (measured at 1M rows, from the finest level: 46.9 ->
+        // 45.4 ms/step; at 10M rows from level 2: four launches of ~4.4 us become one), plain launches around it
+        for (size_t l = 0; l < lt; ++l) {
+            if (ra.nlev > 1 && l == ls) {
+                const int32_t nl = l == 0 ? n_top : H.lv[l].n;
+                const dim3 gf(std::min((nl + kBlock - 1) / kBlock, 2048));
+                if (l == 0) hipLaunchKernelGGL(k_amg_restrict4<TR>, gf, dim3(kBlock), 0, c->stream, nl, rin, ra, done);
+                else hipLaunchKernelGGL(k_amg_restrict4<float>, gf, dim3(kBlock), 0, c->stream, nl, (const float*)H.lv[l].r, ra, done);
+                l += (size_t)ra.nlev - 1;
+                continue;
+            }
             const AmgXfer& X = H.xf[l];
             float* rc = X.dense ? H.cr : X.onto_global ? H.rep_rglob + H.rep_row0 : H.lv[l + 1].r;
             const dim3 g(small_grid(X.n_coarse));
@@ -1144,7 +1303,9 @@ static hipError_t amg_vcycle_t(Ctx* c, AmgHierarchy& H, const TR* rin, float* zo
         // first sweep on A*P: its columns are the coarser level's columns, so a decomposed coarser level must
         // exchange its result first (a smaller message than exchanging the prolongated vector); the replicated
         // level's result is complete on every subdomain
-        const bool fused = X.with_ap && !X.dense && (!H.distributed || X.onto_global || (int)(l + 1) < H.halo_levels);
+        // (towards a SHARED dense level of a decomposed hierarchy the solve leaves only this subdomain's rows behind;
+        //  a hierarchy's own dense level is an ordinary coarse vector)
+        const bool fused = X.with_ap && (H.distributed ? !X.dense && (X.onto_global || (int)(l + 1) < H.halo_levels) : true);
         // frozen-ghost smoothing (AmgHierarchy::frozen_ghosts): the first sweep also writes this level's ghost columns,
         // alpha * e[coarse column of the ghost], and no sweep of the level exchanges
         const bool frozen = halo && fused && ((H.frozen_mask >> std::min<size_t>(l, 30)) & 1u) && X.ghost_col != nullptr;
@@ -1167,6 +1328,12 @@ static hipError_t amg_vcycle_t(Ctx* c, AmgHierarchy& H, const TR* rin, float* zo
             const bool four = H.top_four && H.coarse4;
             const float omega = four ? (float)(H.c4[0] / l4) : w1;
             const float w2 = four ? (float)(H.c4[1] / l4) : w2_fine;
+            const float w4[4] = {(float)(H.c4[0] / l4), (float)(H.c4[1] / l4), (float)(H.c4[2] / l4), (float)(H.c4[3] / l4)};
+            if (four && fused && !halo && l < H.sw.size()) {
+                PhaseTimer t(c, ph(SHK_PH_AMG_FINE));
+                if (launch_sweeps<TR>(c, H.sw[l], A, H.top_vals, H.top_dinv, rin, X, e_cols, agg_off, false, zout, w4, alpha, done))
+                    return hipSuccess;
+            }
             if (fused) {
                 AmgFirstArgs<TR> f{DevSell{X.n_fine, X.n_coarse_cols, X.ap_nslice, sell_fits_cache(X.ap_slots, kAmgSlotBytes),
                                            X.ap_ptr, X.ap_col, X.ap_rowlen, X.ap_cbase, X.ap_ptr16, X.ap_col16},
@@ -1206,6 +1373,13 @@ static hipError_t amg_vcycle_t(Ctx* c, AmgHierarchy& H, const TR* rin, float* zo
             const bool more = H.coarse4 && (int)l >= H.coarse4_from;
             const float lw1 = more ? (float)(H.c4[0] / l4) : w1;
             const float lw2 = more ? (float)(H.c4[1] / l4) : w2;
+            if (fused && more && (frozen || A.n_cols == A.n_rows) && l < H.sw.size()) {
+                const float w4[4] = {lw1, lw2, (float)(H.c4[2] / l4), (float)(H.c4[3] / l4)};
+                PhaseTimer t(c, ph_level(l));
+                if (launch_sweeps<float>(c, H.sw[l], A, L.vals, L.dinv, (const float*)L.r, X, e_cols, agg_off, frozen, L.x2, w4,
+                                         alpha, done))
+                    return hipSuccess;
+            }
             if (fused) {
                 AmgFirstArgs<float> f{DevSell{X.n_fine, X.n_coarse_cols, X.ap_nslice, sell_fits_cache(X.ap_slots, kAmgSlotBytes),
                                               X.ap_ptr, X.ap_col, X.ap_rowlen, X.ap_cbase, X.ap_ptr16, X.ap_col16},
@@ -1510,7 +1684,7 @@ int amg_setup_distributed(Ctx* c, std::string& err) {
         H.rep = new AmgHierarchy();
         H.rep->top_four = true;
         if ((e = amg_upload_rep_top(c, *H.rep, G, G_diag)) != hipSuccess ||
-            (e = amg_upload(c, rplans, *H.rep, G.n_rows, &ident)) != hipSuccess) { err = hipGetErrorString(e); return -1; }
+            (e = amg_upload(c, rplans, *H.rep, G.n_rows, &ident, &G)) != hipSuccess) { err = hipGetErrorString(e); return -1; }
     }
     if (wait_stream(c) != hipSuccess) { err = "synchronize"; return -1; }
     return 0;

@@ -142,9 +142,29 @@ static void set_poly_rule(Ctx* c) {
     }
 }
 
+// Fused multi-sweep smoother of one level: built on the host from the level's pattern, uploaded if the level allows it.
+static hipError_t upload_sweep_plan(Ctx* c, const SellPattern& A, const SellPattern& AP, DevSweepPlan& D) {
+    D = DevSweepPlan();
+    if (!tunables().amg_fused_sweeps || AP.n_rows != A.n_rows) return hipSuccess;
+    // the fused launch pays where a sweep is launch-bound; a level too large for that keeps its streaming sweeps
+    // (measured at 10M rows, us per cycle in four launches / in one: level 5 of 9.8k rows 26 / 14, level 4 of 39k 26 / 16,
+    //  level 3 of 156k 31 / 22, level 2 of 625k 51 / 63, level 1 of 2.5M 142 / 223: SHK_AMG_FUSED_ROWS = 200 000)
+    if (A.n_rows > tunables().amg_fused_rows) return hipSuccess;
+    SweepPlan P;
+    if (!build_sweep_plan(A, AP, P).empty() || P.nblk == 0) return hipSuccess;   // no plan: one launch per sweep
+    hipError_t e;
+    if ((e = upload(c, &D.hdr, P.hdr)) != hipSuccess) return e;
+    if ((e = upload(c, &D.ext_info, P.ext_info)) != hipSuccess) return e;
+    if ((e = upload(c, &D.lcol_own, P.lcol_own)) != hipSuccess) return e;
+    if ((e = upload(c, &D.ring_lcol, P.ring_lcol)) != hipSuccess) return e;
+    D.nblk = P.nblk; D.width = P.width; D.max_local = P.max_local;
+    return hipSuccess;
+}
+
 namespace shk {
 hipError_t amg_upload_rep_top(Ctx* c, AmgHierarchy& R, const SellPattern& G, const std::vector<int32_t>& diag_slot) {
     hipError_t e;
+
     if ((e = upload(c, &R.t_ptr, G.ptr)) != hipSuccess) return e;
     if ((e = upload(c, &R.t_col, G.col)) != hipSuccess) return e;
     if ((e = upload(c, &R.t_rowlen, G.rowlen)) != hipSuccess) return e;
@@ -164,12 +184,15 @@ hipError_t amg_upload_rep_top(Ctx* c, AmgHierarchy& R, const SellPattern& G, con
 }
 
 hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H, int64_t n_loc0,
-                      const std::vector<int32_t>* krank0) {
+                      const std::vector<int32_t>* krank0, const SellPattern* top) {
     const std::vector<int32_t>& kr0 = krank0 ? *krank0 : c->plan.krank;
     hipError_t e;
     const size_t nx = plans.size();
     H.xf.resize(nx);
     H.lv.resize(nx);  // [0] unused; sparse levels 1 .. nx-1
+    if (H.sw.size() < nx) H.sw.resize(nx);
+    SellPattern Aprev;            // pattern of the level the current transfer starts from (level l), kept for its sweep plan
+    bool have_prev = false;
     std::vector<int32_t> prev_pos, prev_rank;
     for (size_t l = 0; l < nx; ++l) {
         AmgLevelPlan& LP = plans[l];
@@ -180,7 +203,7 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
         if ((e = upload(c, &X.members, LP.members)) != hipSuccess) return e;
         if ((e = upload(c, &X.gptr, LP.gptr)) != hipSuccess) return e;
         if ((e = upload(c, &X.glist, LP.glist)) != hipSuccess) return e;
-        if (l < (size_t)kFusedRestrict) {
+        {
             // tables of the fused restriction, indexed by k-d rank; they rely on rank k's members sitting in the
             // 256-row group k / 64 of the finer level (true for every hierarchy built here; checked anyway)
             const int32_t nc = LP.n_coarse;
@@ -212,6 +235,10 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
             }
         }
         if (LP.with_ap) {
+            // fused four-sweep smoother of level l (its first sweep runs on this transfer's A*P): coarse levels, and the
+            // top level of a replicated hierarchy (`top`), which is a coarse level of the whole cycle
+            if (l >= 1 && have_prev && (e = upload_sweep_plan(c, Aprev, LP.AP, H.sw[l])) != hipSuccess) return e;
+            if (l == 0 && top && (e = upload_sweep_plan(c, *top, LP.AP, H.sw[0])) != hipSuccess) return e;
             X.with_ap = true; X.ap_nslice = LP.AP.nslice; X.ap_slots = LP.AP.slots;
             if (l == 0) H.ap_nnz0 = LP.AP.nnz;
             if ((e = upload(c, &X.ap_ptr, LP.AP.ptr)) != hipSuccess) return e;
@@ -246,6 +273,8 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
             if ((e = upload(c, &L.ptr16, LP.Ac.ptr16)) != hipSuccess) return e;
             if ((e = upload(c, &L.col16, LP.Ac.col16)) != hipSuccess) return e;
             if ((e = upload(c, &L.diag_slot, LP.diag_slot)) != hipSuccess) return e;
+            Aprev = std::move(LP.Ac);
+            have_prev = true;
             const size_t nr = std::max<size_t>((size_t)L.nslice * kSlice, (size_t)L.n_cols);
             if ((e = dev_alloc(c, &L.vals, (size_t)L.slots)) != hipSuccess) return e;
             float** vs[] = {&L.dinv, &L.x, &L.x2, &L.x3, &L.r};

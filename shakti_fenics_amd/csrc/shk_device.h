@@ -335,6 +335,13 @@ struct AmgXfer {  // level l -> l+1
     int32_t* ghost_col = nullptr;
     int32_t n_ghost = 0;
 };
+// Device copy of a SweepPlan (shk_plan.h): the fused multi-sweep smoother of one level.
+struct DevSweepPlan {
+    int32_t nblk = 0, width = 0, max_local = 0;
+    int32_t *hdr = nullptr, *ext_info = nullptr;
+    uint16_t *lcol_own = nullptr, *ring_lcol = nullptr;
+    bool ready() const { return nblk > 0; }
+};
 // A hierarchy is either block-local (the owned diagonal block of a subdomain, or the whole matrix of a single
 // context: no communication) or distributed (ghost columns kept on every level, per-level halo plans, one
 // dense coarsest operator shared by all subdomains).
@@ -346,6 +353,7 @@ struct AmgHierarchy {
     std::vector<AmgLevel> lv;    // [0] unused, [l] = sparse coarse level l
     std::vector<AmgXfer> xf;     // [l] : level l -> l+1; the last one lands on the dense coarsest level
     std::vector<int> plan_of;    // distributed: index into Comm::plans of level l's halo plan (size = xf.size())
+    std::vector<DevSweepPlan> sw;   // [l]: fused four-sweep smoother of sparse level l >= 1 ([0]: a replicated hierarchy's top)
     bool distributed = false;
     double alpha = 1.5;          // over-correction x = alpha * P e_c: piecewise-constant prolongation under-estimates
                                  // the coarse correction.  Measured ms/step at 10M | 1M rows: alpha 1.0: 870 | 108,
@@ -608,7 +616,9 @@ hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense, bool d
 hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout);
 // upload one host hierarchy (shk_api.hip: owns the allocation helpers)
 hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H, int64_t n_loc0,
-                      const std::vector<int32_t>* krank0 = nullptr);   // krank0: k-d ranks of the top rows (default: the mesh's)
+                      const std::vector<int32_t>* krank0 = nullptr,    // krank0: k-d ranks of the top rows (default: the mesh's)
+                      const SellPattern* top = nullptr);               // pattern of the top operator when it is itself a coarse
+                                                                       // level of a larger cycle (replicated hierarchy)
 hipError_t amg_upload_rep_top(Ctx* c, AmgHierarchy& R, const SellPattern& G, const std::vector<int32_t>& diag_slot);
 hipError_t allreduce_parts(Ctx* c, int first, int nslots);
 hipError_t allreduce_part_arrays(Ctx* c, const double* part, double* red, int nslots);   // any partial arrays -> scalars

@@ -745,6 +745,82 @@ std::string coarsen_onto_global(const SellPattern& Af, const std::vector<int32_t
     return std::string();
 }
 
+std::string build_sweep_plan(const SellPattern& A, const SellPattern& AP, SweepPlan& out) {
+    out = SweepPlan();
+    const int32_t n = A.n_rows;
+    // no plan (the cycle keeps one launch per sweep) unless the rows fit the kernel's register rows
+    if (n < 1 || A.max_row_len > kSweepMaxWidth || AP.n_rows != n || AP.max_row_len > kSweepMaxWidthAP) return std::string();
+    const int32_t nblk = (n + kSweepRows - 1) / kSweepRows;
+    const int W = A.max_row_len;
+    std::vector<int32_t> stamp((size_t)A.n_cols, -1), lid((size_t)A.n_cols, 0);
+    std::vector<int32_t> ring[3], fixed;
+    SweepPlan P;
+    P.width = W;
+    P.hdr.reserve((size_t)8 * nblk);
+    P.lcol_own.assign((size_t)A.slots, 0);
+    auto columns = [&](int32_t i, auto&& f) {
+        const int32_t s = i / kSlice, l = i % kSlice, base = A.ptr[s];
+        for (int k = 0; k < A.rowlen[i]; ++k) f(k, A.col[base + k * kSlice + l]);
+    };
+    for (int32_t b = 0; b < nblk; ++b) {
+        const int32_t r0 = b * kSweepRows, r1 = std::min(n, r0 + kSweepRows), n0 = r1 - r0;
+        for (auto& v : ring) v.clear();
+        fixed.clear();
+        for (int32_t i = r0; i < r1; ++i) { stamp[i] = b; lid[i] = i - r0; }
+        // ring k+1 = columns of the rows of ring k (ring 0 = the block) not seen yet; ghost columns are constants
+        for (int k = 0; k < 3; ++k) {
+            auto visit = [&](int, int32_t c) {
+                if (stamp[c] == b) return;
+                stamp[c] = b;
+                if (c >= n) fixed.push_back(c); else ring[k].push_back(c);
+            };
+            if (k == 0) for (int32_t i = r0; i < r1; ++i) columns(i, visit);
+            else for (int32_t i : ring[k - 1]) columns(i, visit);
+        }
+        // (the columns of ring-3 rows are never read: their first-sweep value comes from the A*P operator alone)
+        // local indices: the block's rows 0 .. n0-1, ring rows from kSweepRows on (also in a last, shorter block: thread
+        // tid of the kernel owns local rows tid, tid + 256, tid + 512), fixed entries behind them
+        int32_t next = kSweepRows;
+        for (auto& v : ring) for (int32_t i : v) lid[i] = next++;
+        const int32_t nS2 = kSweepRows + (int32_t)(ring[0].size() + ring[1].size()), nS3 = next;
+        for (int32_t c : fixed) lid[c] = next++;
+        if (next > kSweepMaxLocal || nS2 > kSweepMaxS2 || nS3 > kSweepMaxS3 || (int32_t)fixed.size() > kSweepRows)
+            return std::string();   // too irregular for the kernel's fixed row slots: no plan
+        P.max_local = std::max(P.max_local, next);
+        const int32_t hdr[8] = {(int32_t)(P.ext_info.size() / 4), (int32_t)(P.ring_lcol.size() / W), (int32_t)ring[0].size(),
+                                (int32_t)ring[1].size(), (int32_t)ring[2].size(), (int32_t)fixed.size(), 0, 0};
+        P.hdr.insert(P.hdr.end(), hdr, hdr + 8);
+        for (auto& v : ring)
+            for (int32_t i : v) {
+                const int32_t info[4] = {i, A.ptr[i / kSlice] + i % kSlice, AP.ptr[i / kSlice] + i % kSlice,
+                                         (int32_t)A.rowlen[i] | ((int32_t)AP.rowlen[i] << 8)};
+                P.ext_info.insert(P.ext_info.end(), info, info + 4);
+            }
+        for (int32_t c : fixed) { const int32_t info[4] = {c, 0, 0, 0}; P.ext_info.insert(P.ext_info.end(), info, info + 4); }
+        P.ring_rows += (int64_t)(ring[0].size() + ring[1].size() + ring[2].size());
+        // block-local column indices: own rows per SELL slot (padding slots point at the row itself, value 0) ...
+        for (int32_t i = r0; i < r1; ++i) {
+            const int32_t s = i / kSlice, l = i % kSlice, base = A.ptr[s];
+            const int w = (A.ptr[s + 1] - base) / kSlice;
+            for (int k = 0; k < w; ++k) {
+                const int32_t slot = base + k * kSlice + l;
+                P.lcol_own[slot] = (uint16_t)(k < A.rowlen[i] ? lid[A.col[slot]] : lid[i]);
+            }
+        }
+        // ... and the rows of rings 1 and 2 (the ones later sweeps recompute), `width` entries each
+        for (int k = 0; k < 2; ++k)
+            for (int32_t i : ring[k]) {
+                const size_t at = P.ring_lcol.size();
+                P.ring_lcol.resize(at + W, (uint16_t)lid[i]);
+                columns(i, [&](int kk, int32_t c) { P.ring_lcol[at + kk] = (uint16_t)lid[c]; });
+            }
+        if (P.ring_lcol.size() / W > (size_t)INT32_MAX / 2 || P.ext_info.size() / 4 > (size_t)INT32_MAX / 2) return std::string();
+    }
+    P.nblk = nblk;
+    out = std::move(P);
+    return std::string();
+}
+
 void sell_to_csr(const HostPlan& P, const double* sell_vals, std::vector<int32_t>& rowptr,
                  std::vector<int32_t>& colidx, std::vector<double>* vals) {
     const SellPattern& A = P.A;

@@ -78,6 +78,34 @@ struct AmgLevelPlan {
     std::vector<int32_t> ghost_col;
 };
 
+// Plan of the fused multi-sweep smoother of one sparse multigrid level (shk_amg.hip: k_amg_sweeps).  The level's four
+// damped-Jacobi sweeps run inside ONE launch: a workgroup owns a block of 256 consecutive rows and computes sweep j on
+// the rows within graph distance 4 - j of the block (S3 > S2 > S1 > S0 = the block), so that every value a later sweep
+// reads was produced inside the workgroup -- redundant work on the rings instead of a launch boundary (~4.5 us each on
+// levels whose whole sweep takes less than that) between the sweeps.  Ghost columns of a decomposed level are constants
+// of the sweeps (frozen-ghost smoothing), listed per block as `fixed` entries.
+constexpr int kSweepRows = 256;        // rows of a block (4 SELL slices) = threads of its workgroup
+constexpr int kSweepMaxS2 = 2 * kSweepRows;   // a thread recomputes at most 2 rows (its own + one ring row) in sweeps 2-4 ...
+constexpr int kSweepMaxS3 = 3 * kSweepRows;   // ... and at most 3 in the first sweep
+constexpr int kSweepMaxLocal = 1024;   // most local entries (S3 + fixed) a block may address; beyond it the level falls back
+constexpr int kSweepMaxWidth = 16;     // longest row of A the kernel keeps in registers (12- and 16-wide instances)
+constexpr int kSweepMaxWidthAP = 8;    // longest row of A*P
+struct SweepPlan {
+    int32_t nblk = 0;                  // 0: no plan (level too irregular, or rows longer than the kernel's register rows)
+    int32_t width = 0;                 // stride of ring_lcol = longest row of the level
+    int32_t max_local = 0;             // largest S3 + fixed over the blocks
+    std::vector<int32_t> hdr;          // 8 per block: first entry in ext_info, first row in ring_lcol, rows of ring 1, 2, 3,
+                                       // fixed entries, 0, 0
+    std::vector<int32_t> ext_info;     // 4 per extended entry of a block, rings 1, 2, 3 then the fixed columns:
+                                       // ring row {row, its first slot in A, its first slot in A*P, len(A) | len(A*P) << 8};
+                                       // fixed {column, 0, 0, 0} -- ONE 16-byte load tells a thread everything about its row
+    std::vector<uint16_t> lcol_own;    // per SELL slot of the level: block-local index of the slot's column
+    std::vector<uint16_t> ring_lcol;   // width per ring-1 / ring-2 row: block-local indices of its columns
+    int64_t ring_rows = 0;             // sum over blocks of rings 1..3 (the redundant first-sweep rows)
+};
+// AP: the A*P operator of the level's first sweep (same rows as A)
+std::string build_sweep_plan(const SellPattern& A, const SellPattern& AP, SweepPlan& out);
+
 struct HostPlan {
     int64_t n_own = 0, n_loc = 0, ne = 0;
     std::vector<int32_t> krank;        // k-d rank of each internal owned vertex (aggregate = krank / 4)
