@@ -45,7 +45,10 @@ def parse():
                     help="timed steps; 8 = one rebuild period of the multigrid's dense coarsest inverse, so the default "
                          "run pays for exactly one rebuild inside the timed region")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="c4_10m", help="c1_5k | c1_12k | c2_1m | c4_10m (default: the 10M-DOF mesh)")
+    ap.add_argument("--config", default="c4_10m", help="c1_5k | c1_12k | c2_1m | c4_10m (default: the 10M-DOF jittered rectangle) | "
+                    "basin_1m | basin_10m (genuinely unstructured Delaunay basin mesh on the same footprint)")
+    ap.add_argument("--window-steps", type=int, default=25, help="N=1: steps run in all (plain steps are appended after the timed "
+                    "region) so that the line can also report the windows 'steps 1-8' and 'steps 5-24' whatever --steps/--warmup say")
     ap.add_argument("--order", default="morton")
     ap.add_argument("--dt", type=float, default=3600.0)
     ap.add_argument("--storage", type=int, default=0, help="lake storage term on (C3) or off (steady-state march)")
@@ -115,10 +118,10 @@ def cpu_baseline(args) -> dict:
     BiCGStab solver on C1 (at 62k DOF it already needs ~1900 iterations per Newton iteration and minutes per step).  This is the only place bench.py touches oracle/."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from shakti_fenics_amd.mesh import rectangle_mesh
-    from shakti_fenics_amd.synthetic import CONFIGS, config_mesh
+    from shakti_fenics_amd.synthetic import BASIN_CONFIGS, CONFIGS, config_mesh
 
     nx, ny = (int(v) for v in args.cpu_sample.split("x"))
-    _, _, Lx, Ly = CONFIGS[args.config]
+    Lx, Ly = (BASIN_CONFIGS[args.config][1:] if args.config in BASIN_CONFIGS else CONFIGS[args.config][2:])
     sample = rectangle_mesh(nx, ny, Lx, Ly, order=args.order)
     head = _oracle_leg(sample, bool(args.storage), 5, args.dt, "lu")
     legs = {"sample_lu": head}
@@ -183,9 +186,23 @@ def main():
             print(f"[bench +{time.perf_counter() - t_start:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
     t_start = time.perf_counter()
-    run = make_runner(args, rank, world, local_rank)
+    try:
+        run = make_runner(args, rank, world, local_rank)
+    except _lib.ShaktiCommStall as exc:
+        _lib.exit_on_stall(exc)
     run.ctx.set_params(krylov_warm_start=args.warm_start)
     say(f"setup done: {run.describe()}")
+    switches = _lib.env_overrides()
+    if switches:
+        say(f"SHK_* experiment switches set in the environment: {switches}")
+    wiring = None
+    if world > 1:
+        # every rank's wiring (device, neighbours, ghost counts) after the start-up exchange + all-reduce check
+        wiring = [None] * world
+        dist.all_gather_object(wiring, run.wiring)
+        for w in wiring:
+            say(f"rank {w['rank']}: device {w['device']}, {w['n_own']} owned + {w['n_ghost']} ghost vertices, neighbours {w['neighbours']}, "
+                f"ghosts per neighbour {w['ghosts_per_neighbour']}")
 
     def barrier():
         run.sync()
@@ -194,20 +211,35 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # host time stamps after every step (no extra synchronisation: a step returns after its last residual norm, its update
+    # kernels -- ~0.5 ms -- run into the next step): lets the line report fixed windows of steps beside the timed region
+    stamps, counts = [time.perf_counter()], []
+
+    def one_step(i):
+        try:
+            info = run.step(i)
+        except _lib.ShaktiCommStall as exc:
+            _lib.exit_on_stall(exc)
+        stamps.append(time.perf_counter())
+        counts.append((info.newton_its, info.krylov_its))
+        return info
+
     for i in range(args.warmup):
-        info = run.step(i)
+        info = one_step(i)
         say(f"warmup step {i}: newton {info.newton_its} krylov {info.krylov_its}")
     barrier()
+    stamps[-1] = time.perf_counter()
     st0 = run.ctx.comm_stats() if world > 1 else None
     t0 = time.perf_counter()
     newton = krylov = 0
     for i in range(args.warmup, args.warmup + args.steps):
-        info = run.step(i)
+        info = one_step(i)
         newton += info.newton_its
         krylov += info.krylov_its
         say(f"timed step {i}: newton {info.newton_its} krylov {info.krylov_its}")
     barrier()
     wall = time.perf_counter() - t0
+    stamps[-1] = time.perf_counter()
     st1 = run.ctx.comm_stats() if world > 1 else None
     if world > 1:
         t = torch.tensor([wall], dtype=torch.float64, device="cpu" if args.transport == "gloo" else "cuda")
@@ -244,9 +276,39 @@ def main():
             "parallelism": f"dd{world}" if world > 1 else "single",
         },
     }
+    out["env_overrides"] = switches or None
+    if world == 1:
+        # the same transient read through fixed windows: the timed region above is whatever --steps / --warmup say (the
+        # driver's command: 20 after 5; the default: 8 after 1), and the metric counts Newton iterations, which fall from
+        # 5 to 2 per step over the first hours of the transient -- so both windows are always reported
+        while len(counts) < args.window_steps:
+            one_step(len(counts))
+        run.sync()
+        stamps[-1] = time.perf_counter()
+
+        def window(a, b):   # steps a .. b inclusive
+            if b >= len(counts):
+                return None
+            w = stamps[b + 1] - stamps[a]
+            nn, kk = sum(c[0] for c in counts[a:b + 1]), sum(c[1] for c in counts[a:b + 1])
+            return {"steps": f"{a}-{b}", "value": nv * nn / w, "unit": "DOF-updates/s", "ms_per_step": 1e3 * w / (b - a + 1),
+                    "newton_its": nn, "krylov_its": kk}
+        out["windows"] = {"steps_1_8": window(1, 8), "steps_5_24": window(5, 24),
+                          "note": "host time stamps per step, no synchronisation added; `value` above is the timed region "
+                                  f"(steps {args.warmup}-{args.warmup + args.steps - 1})",
+                          "per_step": [{"newton_its": c[0], "krylov_its": c[1], "ms": 1e3 * (stamps[i + 1] - stamps[i])}
+                                       for i, c in enumerate(counts)]}
     if world > 1:
+        out["ranks"] = wiring
         st = {k: v - st0[k] for k, v in st1.items()}
         nk = max(krylov, 1)
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {k: v / nk for k, v in st.items()})
+        for r, m in enumerate(per_rank):
+            say(f"rank {r}: per Krylov iteration {m['exchanges']:.1f} ghost exchanges, {m['allreduces']:.1f} all-reduces, "
+                f"{m['allgathers']:.1f} all-gathers; {m['bytes_exchanged'] / 1e3:.1f} KB exchanged, {m['bytes_allreduced'] / 1e3:.2f} KB "
+                f"all-reduced, {m['bytes_allgathered'] / 1e3:.1f} KB all-gathered")
+        out["message_rounds_by_rank"] = per_rank
         out["message_rounds"] = {"rank": 0, "ghost_exchanges_per_krylov_it": st["exchanges"] / nk,
                                  "allreduces_per_krylov_it": st["allreduces"] / nk,
                                  "allgathers_per_krylov_it": st["allgathers"] / nk,
@@ -280,7 +342,7 @@ def main():
         if rank == 0:
             out["roofline"] = roof
         say("roofline step done")
-    if world == 1 and args.steady_max > 0 and args.precond != "jacobi":
+    if world == 1 and args.steady_max > 0 and args.precond != "jacobi" and args.config not in ("basin_10m", "basin_1m"):
         out["steady_state"] = steady_march(run, args, say)
     if world == 1 and args.precond == "jacobi" and args.amg_steps > 0:
         # same state, same metric, with the multigrid preconditioner of DESIGN.md section 9

@@ -109,6 +109,9 @@ enum shk_phase {
 typedef struct shk_profile {
     double ms[SHK_PH_COUNT];      /* summed launch durations per phase */
     int64_t launches[SHK_PH_COUNT];
+    double bytes[SHK_PH_COUNT];   /* bytes those launches HAD to move (what this implementation streams: padded SELL slots,
+                                     16-bit columns, float preconditioner data, every vector once per kernel that reads or
+                                     writes it; re-reads served by caches are not counted) -- with ms: HBM utilisation */
 } shk_profile;
 
 const char* shk_last_error(void);
@@ -155,6 +158,11 @@ int shk_comm_selftest(shk_ctx* ctx);
  * those of the subdomain: one rank of a P-way decomposition can be timed alone on one GPU (tools/scaling_model.py).
  * shk_step / shk_newton_solve report what they computed; nothing in the product path turns this on. */
 int shk_comm_set_timing_only(shk_ctx* ctx, int32_t on);
+/* Start-up check of the reduction path (either transport): value[0] is summed over the subdomains through the SAME
+ * all-reduce the Krylov loop uses, on the context's stream, and the host wait goes through the RCCL deadline
+ * (SHK_COMM_TIMEOUT_S): a mis-wired communicator fails here with an error instead of hanging the first solve.  The ghost
+ * exchange has its own check in shk_halo_update on a field of known values (shakti_fenics_amd/distributed.py). */
+int shk_comm_allreduce_check(shk_ctx* ctx, double* value);
 /* What the RCCL deadline does when it fires, exposed for hosts that detect a dead peer themselves (and for tests): marks
  * the context POISONED.  Every later call that would wait for the device fails at once, and shk_destroy returns without
  * synchronising, destroying the communicator (ncclCommAbort if available) or freeing device memory -- all of which

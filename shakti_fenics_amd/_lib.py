@@ -55,7 +55,7 @@ PRECOND = dict(jacobi=0, amg=1, amg_local=2)
 
 
 class shk_profile(C.Structure):
-    _fields_ = [("ms", C.c_double * len(PHASES)), ("launches", C.c_int64 * len(PHASES))]
+    _fields_ = [("ms", C.c_double * len(PHASES)), ("launches", C.c_int64 * len(PHASES)), ("bytes", C.c_double * len(PHASES))]
 
 
 FIELDS = dict(N=0, N_n=1, b=2, q=3, z_b=4, z_s=5, G=6, melt_n=7, storage=8, inputs=9, qx=10, qy=11, dx=12)
@@ -67,7 +67,7 @@ EXPORTS = (
     "shk_assemble", "shk_get_residual", "shk_csr_nnz", "shk_get_csr", "shk_linear_solve", "shk_spmv",
     "shk_newton_solve", "shk_update_explicit", "shk_step", "shk_sync", "shk_profile_enable",
     "shk_profile_read", "shk_time_kernel", "shk_plan_stats", "shk_set_halo", "shk_comm_unique_id",
-    "shk_comm_init_rccl", "shk_comm_init_callbacks", "shk_comm_selftest", "shk_comm_set_timing_only", "shk_comm_mark_stalled", "shk_env_overrides", "shk_tunable_set", "shk_comm_stats", "shk_comm_overlap", "shk_halo_update", "shk_interp_regular_grid",
+    "shk_comm_init_rccl", "shk_comm_init_callbacks", "shk_comm_selftest", "shk_comm_set_timing_only", "shk_comm_mark_stalled", "shk_comm_allreduce_check", "shk_env_overrides", "shk_tunable_set", "shk_comm_stats", "shk_comm_overlap", "shk_halo_update", "shk_interp_regular_grid",
     "shk_points_in_polygon",
 )
 
@@ -127,6 +127,7 @@ def load():
         "shk_comm_selftest": ([vp], C.c_int),
         "shk_comm_set_timing_only": ([vp, i32], C.c_int),
         "shk_comm_mark_stalled": ([vp], C.c_int),
+        "shk_comm_allreduce_check": ([vp, P(dbl)], C.c_int),
         "shk_env_overrides": ([C.c_char_p, i64], i64),
         "shk_tunable_set": ([C.c_char_p, C.c_char_p], C.c_int),
         "shk_interp_regular_grid": ([C.c_int, i64, vp, vp, i64, i64, vp, vp, vp, i32, vp], C.c_int),
@@ -406,6 +407,12 @@ class ShaktiHip:
         """Measurement aid (tools/scaling_model.py): messages are skipped, results become wrong, durations stay right."""
         self._check(self.lib.shk_comm_set_timing_only(self._h, 1 if on else 0))
 
+    def comm_allreduce_check(self, value: float) -> float:
+        """Sum of `value` over the subdomains through the Krylov loop's own all-reduce path (start-up check)."""
+        v = C.c_double(float(value))
+        self._check(self.lib.shk_comm_allreduce_check(self._h, C.byref(v)))
+        return v.value
+
     def comm_mark_stalled(self):
         self._check(self.lib.shk_comm_mark_stalled(self._h))
 
@@ -431,9 +438,10 @@ class ShaktiHip:
     def profile_read(self, reset: bool = True) -> dict:
         p = shk_profile()
         self._check(self.lib.shk_profile_read(self._h, C.byref(p), 1 if reset else 0))
-        out = {name: dict(ms=p.ms[i], launches=p.launches[i]) for i, name in enumerate(PHASES)}
+        out = {name: dict(ms=p.ms[i], launches=p.launches[i], bytes=p.bytes[i]) for i, name in enumerate(PHASES)}
         # every multigrid kernel below the finest level, as one figure (what rounds 1-2 called amg_coarse)
-        out["amg_coarse"] = dict(ms=sum(out[k]["ms"] for k in COARSE_PHASES), launches=sum(out[k]["launches"] for k in COARSE_PHASES))
+        out["amg_coarse"] = dict(ms=sum(out[k]["ms"] for k in COARSE_PHASES), launches=sum(out[k]["launches"] for k in COARSE_PHASES),
+                                 bytes=sum(out[k]["bytes"] for k in COARSE_PHASES))
         return out
 
     def time_kernel(self, phase: str, reps: int, dt: float = 3600.0) -> float:

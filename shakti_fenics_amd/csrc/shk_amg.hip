@@ -88,6 +88,7 @@ __global__ __launch_bounds__(kBlock) void k_galerkin(int64_t nslots, const int32
 template <class TC>
 static void launch_galerkin(Ctx* c, int kind, int64_t nslots, const int32_t* gptr, const int32_t* glist, const float* fine, TC* coarse) {
     const Tunables& T = tunables();
+    note_bytes(c, 4.0 * (double)(nslots + 1) + (double)sizeof(TC) * (double)nslots);   // + the gather lists, noted by the caller
     const int contig = T.gal_contig[kind];
     const int ilp = T.gal_ilp[kind];
     const int g = (int)std::min<int64_t>(T.gal_grid[kind], std::max<int64_t>(1, (nslots + (int64_t)ilp * kBlock - 1) / ((int64_t)ilp * kBlock)));
@@ -986,6 +987,7 @@ static void bind_top_to_jacobian(Ctx* c, AmgHierarchy& H) {
     H.topA = c->sell32();
     H.top_vals = c->d_vals32;
     H.top_dinv = c->d_dinv32;
+    H.top_bytes = sell_bytes(c->slots, c->slots16, c->plan.A.nslice, 4);
 }
 
 hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense, bool decided, bool top_only) {
@@ -997,6 +999,7 @@ hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense, bool d
     const bool reuse = tunables().amg_reuse;
     if (top_only && reuse && primary && !refresh_dense && !decided && H.lambda != 0.0) {
         PhaseTimer t(c, SHK_PH_OTHER);
+        note_bytes(c, 12.0 * (double)c->slots + 12.0 * (double)c->n_own);
         hipLaunchKernelGGL(k_narrow, dim3(c->grid), dim3(kBlock), 0, c->stream, c->slots, c->d_vals, c->d_vals32);
         hipLaunchKernelGGL(k_narrow, dim3(small_grid(c->n_own)), dim3(kBlock), 0, c->stream, c->n_own, c->d_dinv, c->d_dinv32);
         return hipSuccess;
@@ -1021,12 +1024,15 @@ hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense, bool d
     }
     PhaseTimer t(c, SHK_PH_OTHER);
     if (primary) {
+        note_bytes(c, 12.0 * (double)c->slots + 12.0 * (double)c->n_own);
         hipLaunchKernelGGL(k_narrow, dim3(c->grid), dim3(kBlock), 0, c->stream, c->slots, c->d_vals, c->d_vals32);
         hipLaunchKernelGGL(k_narrow, dim3(small_grid(c->n_own)), dim3(kBlock), 0, c->stream, c->n_own, c->d_dinv, c->d_dinv32);
     }
     const float* fine = H.top_vals;
     for (size_t l = 0; l < H.xf.size(); ++l) {
         const AmgXfer& X = H.xf[l];
+        // (every finer value is read once by each of the two gather plans: 8 B per list entry)
+        note_bytes(c, 8.0 * (double)(X.n_glist + (X.with_ap ? X.ap_n_glist : 0)));
         if (X.with_ap)
             launch_galerkin<float>(c, 1, X.ap_slots, X.ap_gptr, X.ap_glist, fine, X.ap_vals);
         if (X.onto_global) {
@@ -1141,9 +1147,10 @@ static RestrictArgs amg_restrict_args(const AmgHierarchy& H, size_t lt, size_t* 
 
 template <bool FINE, class TX, class TR, class TO>
 static void launch_post(Ctx* c, const DevSell& A, const float* vals, const float* dinv, const TR* r, const TX* x, TO* xo,
-                        float w, const int* done, int phase = SHK_PH_AMG_FINE) {
+                        float w, const int* done, int phase = SHK_PH_AMG_FINE, double post_bytes = 0.0) {   // post_bytes: the operator's stream
     AmgSmoothArgs<TX, TR, TO> a{A, vals, dinv, r, x, xo, w, done};
     const dim3 g(std::min((A.nslice + 3) / 4, 2048));
+    note_bytes(c, post_bytes + (double)A.n_rows * (sizeof(TX) + sizeof(TR) + 4 + sizeof(TO)));
     if (FINE) launch_phase(c, phase, k_amg_post<FINE, TX, TR, TO>, g, dim3(kBlock), 0, a);
     else hipLaunchKernelGGL((k_amg_post<FINE, TX, TR, TO>), g, dim3(kBlock), 0, c->stream, a);
 }
@@ -1172,7 +1179,7 @@ static hipError_t launch_post_split(Ctx* c, const DevSell& A, const float* vals,
 template <class TR>
 static bool launch_sweeps(Ctx* c, const DevSweepPlan& S, const DevSell& A, const float* vals, const float* dinv, const TR* r,
                           const AmgXfer& X, const float* e_cols, int32_t agg_off, bool frozen, float* xo, const float (&w)[4],
-                          float alpha, const int* done) {
+                          float alpha, const int* done, double a_bytes) {
     if (!S.ready()) return false;
     AmgSweepArgs<TR> a{};
     a.A = A; a.vals = vals; a.dinv = dinv; a.r = r;
@@ -1183,6 +1190,8 @@ static bool launch_sweeps(Ctx* c, const DevSweepPlan& S, const DevSell& A, const
     for (int k = 0; k < 4; ++k) a.w[k] = w[k];
     a.alpha = alpha; a.done = done;
     a.nblk = S.nblk; a.width = S.width; a.hdr = S.hdr; a.ext_info = S.ext_info; a.lcol_own = S.lcol_own; a.ring_lcol = S.ring_lcol;
+    // the operator and A*P streams (the latter with 32-bit columns), the plan arrays, r / 1/diag / agg / result per row
+    note_bytes(c, a_bytes + 8.0 * (double)X.ap_slots + S.plan_bytes + 16.0 * (double)A.n_rows + 4.0 * (double)X.n_coarse_cols);
     const dim3 g(std::min(S.nblk, 8192));
     if (S.width <= 12) hipLaunchKernelGGL((k_amg_sweeps<TR, 12>), g, dim3(kSweepRows), 0, c->stream, a);
     else hipLaunchKernelGGL((k_amg_sweeps<TR, kSweepMaxWidth>), g, dim3(kSweepRows), 0, c->stream, a);
@@ -1223,6 +1232,9 @@ static hipError_t amg_vcycle_t(Ctx* c, AmgHierarchy& H, const TR* rin, float* zo
         for (size_t l = 0; l < lt; ++l) {
             if (ra.nlev > 1 && l == ls) {
                 const int32_t nl = l == 0 ? n_top : H.lv[l].n;
+                double rb = (double)nl * (l == 0 ? sizeof(TR) : 4);
+                for (int j = 0; j < ra.nlev; ++j) rb += 24.0 * (double)ra.nc[j];   // members, position, output
+                note_bytes(c, rb);
                 const dim3 gf(std::min((nl + kBlock - 1) / kBlock, 2048));
                 if (l == 0) hipLaunchKernelGGL(k_amg_restrict4<TR>, gf, dim3(kBlock), 0, c->stream, nl, rin, ra, done);
                 else hipLaunchKernelGGL(k_amg_restrict4<float>, gf, dim3(kBlock), 0, c->stream, nl, (const float*)H.lv[l].r, ra, done);
@@ -1232,6 +1244,7 @@ static hipError_t amg_vcycle_t(Ctx* c, AmgHierarchy& H, const TR* rin, float* zo
             const AmgXfer& X = H.xf[l];
             float* rc = X.dense ? H.cr : X.onto_global ? H.rep_rglob + H.rep_row0 : H.lv[l + 1].r;
             const dim3 g(small_grid(X.n_coarse));
+            note_bytes(c, (double)X.n_fine * (l == 0 ? sizeof(TR) : 4) + 20.0 * (double)X.n_coarse);
             if (l == 0)
                 hipLaunchKernelGGL(k_amg_restrict<TR>, g, dim3(kBlock), 0, c->stream, X.n_coarse, X.members, rin, rc, done);
             else
@@ -1284,6 +1297,7 @@ static hipError_t amg_vcycle_t(Ctx* c, AmgHierarchy& H, const TR* rin, float* zo
             }
             {
                 PhaseTimer t(c, ph(SHK_PH_AMG_DENSE));
+                note_bytes(c, 8.0 * (double)ta.n_c * ta.ncols + 4.0 * (double)(ta.n_c + ta.ncols));
                 hipLaunchKernelGGL(k_dense_gemv<float>, dim3(gemv_grid), dim3(kBlock), 0, c->stream, ta.n_c, ta.row0, ta.ncols,
                                    ta.inv, (const float*)H.cr, ta.cx, done);
             }
@@ -1320,6 +1334,10 @@ static hipError_t amg_vcycle_t(Ctx* c, AmgHierarchy& H, const TR* rin, float* zo
             return e;
         const DevSell A = level_sell(c, H, l);
         const dim3 g(std::min((A.nslice + 3) / 4, 2048));
+        // byte accounting (shk_profile.bytes): the streams of this level's operator and of its A*P
+        const double a_bytes = l == 0 ? H.top_bytes : sell_bytes(H.lv[l].slots, H.lv[l].slots16, H.lv[l].nslice, 4);
+        const double ap_bytes = X.with_ap ? sell_bytes(X.ap_slots, X.ap_slots16, X.ap_nslice, 4) : 0.0;
+        const double first_bytes = ap_bytes + (double)X.n_fine * (4 + (l == 0 ? sizeof(TR) : 4) + 4 + 4) + 4.0 * (double)X.n_coarse_cols;
         if (l == 0) {
             // level 0: right-hand side = the Krylov vector (double); the iterate and the result are float.
             // A replicated hierarchy's top level is a coarse level of the whole cycle: four sweeps, like its peers.
@@ -1331,7 +1349,7 @@ static hipError_t amg_vcycle_t(Ctx* c, AmgHierarchy& H, const TR* rin, float* zo
             const float w4[4] = {(float)(H.c4[0] / l4), (float)(H.c4[1] / l4), (float)(H.c4[2] / l4), (float)(H.c4[3] / l4)};
             if (four && fused && !halo && l < H.sw.size()) {
                 PhaseTimer t(c, ph(SHK_PH_AMG_FINE));
-                if (launch_sweeps<TR>(c, H.sw[l], A, H.top_vals, H.top_dinv, rin, X, e_cols, agg_off, false, zout, w4, alpha, done))
+                if (launch_sweeps<TR>(c, H.sw[l], A, H.top_vals, H.top_dinv, rin, X, e_cols, agg_off, false, zout, w4, alpha, done, a_bytes))
                     return hipSuccess;
             }
             if (fused) {
@@ -1339,6 +1357,7 @@ static hipError_t amg_vcycle_t(Ctx* c, AmgHierarchy& H, const TR* rin, float* zo
                                            X.ap_ptr, X.ap_col, X.ap_rowlen, X.ap_cbase, X.ap_ptr16, X.ap_col16},
                                    X.ap_vals, H.top_dinv, rin, e_cols, X.agg, agg_off, H.x0, omega, alpha, done,
                                    frozen ? X.ghost_col : nullptr, frozen ? X.n_ghost : 0, nullptr};
+                note_bytes(c, first_bytes);
                 launch_phase(c, ph(SHK_PH_AMG_FIRST), k_amg_first<true, TR>, g, dim3(kBlock), 0, f);
             } else {
                 {
@@ -1347,7 +1366,7 @@ static hipError_t amg_vcycle_t(Ctx* c, AmgHierarchy& H, const TR* rin, float* zo
                                        X.n_fine, alpha, X.agg, ec, zout, done);
                 }
                 if (halo && (e = halo_exchange_plan_f32(c, *HP, zout)) != hipSuccess) return e;
-                launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)zout, H.x0, omega, done, ph(SHK_PH_AMG_FINE));
+                launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)zout, H.x0, omega, done, ph(SHK_PH_AMG_FINE), a_bytes);
             }
             if constexpr (sizeof(TR) == sizeof(double)) {
                 if (halo && !frozen && c->overlap && H.plan_of[0] == 0 && A.ptr == c->d_sell_ptr) {
@@ -1357,11 +1376,11 @@ static hipError_t amg_vcycle_t(Ctx* c, AmgHierarchy& H, const TR* rin, float* zo
             }
             if (!split_done) {
                 if (halo && !frozen && (e = halo_exchange_plan_f32(c, *HP, H.x0)) != hipSuccess) return e;
-                launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)H.x0, zout, w2, done, ph(SHK_PH_AMG_FINE));
+                launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)H.x0, zout, w2, done, ph(SHK_PH_AMG_FINE), a_bytes);
             }
             if (four) {
-                launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)zout, H.x0, (float)(H.c4[2] / l4), done, ph(SHK_PH_AMG_FINE));
-                launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)H.x0, zout, (float)(H.c4[3] / l4), done, ph(SHK_PH_AMG_FINE));
+                launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)zout, H.x0, (float)(H.c4[2] / l4), done, ph(SHK_PH_AMG_FINE), a_bytes);
+                launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)H.x0, zout, (float)(H.c4[3] / l4), done, ph(SHK_PH_AMG_FINE), a_bytes);
             }
         } else {
             const AmgLevel& L = H.lv[l];
@@ -1377,7 +1396,7 @@ static hipError_t amg_vcycle_t(Ctx* c, AmgHierarchy& H, const TR* rin, float* zo
                 const float w4[4] = {lw1, lw2, (float)(H.c4[2] / l4), (float)(H.c4[3] / l4)};
                 PhaseTimer t(c, ph_level(l));
                 if (launch_sweeps<float>(c, H.sw[l], A, L.vals, L.dinv, (const float*)L.r, X, e_cols, agg_off, frozen, L.x2, w4,
-                                         alpha, done))
+                                         alpha, done, a_bytes))
                     return hipSuccess;
             }
             if (fused) {
@@ -1386,6 +1405,7 @@ static hipError_t amg_vcycle_t(Ctx* c, AmgHierarchy& H, const TR* rin, float* zo
                                       X.ap_vals, L.dinv, L.r, e_cols, X.agg, agg_off, L.x, lw1, alpha, done,
                                       frozen ? X.ghost_col : nullptr, frozen ? X.n_ghost : 0, L.x2};
                 PhaseTimer t(c, ph_level(l));
+                note_bytes(c, first_bytes);
                 hipLaunchKernelGGL((k_amg_first<false, float>), g, dim3(kBlock), 0, c->stream, f);
             } else {
                 {
@@ -1397,7 +1417,7 @@ static hipError_t amg_vcycle_t(Ctx* c, AmgHierarchy& H, const TR* rin, float* zo
                 // (without the exchange the ghost entries stay zero = block-local smoothing on that level)
                 if (halo && (e = halo_exchange_plan_f32(c, *HP, L.x2)) != hipSuccess) return e;
                 PhaseTimer t(c, ph_level(l));
-                launch_post<false>(c, A, L.vals, L.dinv, (const float*)L.r, (const float*)L.x2, L.x, lw1, done);
+                launch_post<false>(c, A, L.vals, L.dinv, (const float*)L.r, (const float*)L.x2, L.x, lw1, done, 0, a_bytes);
             }
             if (halo && !frozen && (e = halo_exchange_plan_f32(c, *HP, L.x)) != hipSuccess) return e;
             if (halo && !frozen && fused && more) {
@@ -1410,10 +1430,10 @@ static hipError_t amg_vcycle_t(Ctx* c, AmgHierarchy& H, const TR* rin, float* zo
                     return e;
             }
             PhaseTimer t(c, ph_level(l));
-            launch_post<false>(c, A, L.vals, L.dinv, (const float*)L.r, (const float*)L.x, L.x2, lw2, done);
+            launch_post<false>(c, A, L.vals, L.dinv, (const float*)L.r, (const float*)L.x, L.x2, lw2, done, 0, a_bytes);
             if (more) {
-                launch_post<false>(c, A, L.vals, L.dinv, (const float*)L.r, (const float*)L.x2, L.x, (float)(H.c4[2] / l4), done);
-                launch_post<false>(c, A, L.vals, L.dinv, (const float*)L.r, (const float*)L.x, L.x2, (float)(H.c4[3] / l4), done);
+                launch_post<false>(c, A, L.vals, L.dinv, (const float*)L.r, (const float*)L.x2, L.x, (float)(H.c4[2] / l4), done, 0, a_bytes);
+                launch_post<false>(c, A, L.vals, L.dinv, (const float*)L.r, (const float*)L.x, L.x2, (float)(H.c4[3] / l4), done, 0, a_bytes);
             }
         }
         return hipSuccess;

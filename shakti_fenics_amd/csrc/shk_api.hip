@@ -158,6 +158,7 @@ static hipError_t upload_sweep_plan(Ctx* c, const SellPattern& A, const SellPatt
     if ((e = upload(c, &D.lcol_own, P.lcol_own)) != hipSuccess) return e;
     if ((e = upload(c, &D.ring_lcol, P.ring_lcol)) != hipSuccess) return e;
     D.nblk = P.nblk; D.width = P.width; D.max_local = P.max_local;
+    D.plan_bytes = 4.0 * (double)(P.hdr.size() + P.ext_info.size()) + 2.0 * (double)(P.lcol_own.size() + P.ring_lcol.size());
     return hipSuccess;
 }
 
@@ -180,6 +181,7 @@ hipError_t amg_upload_rep_top(Ctx* c, AmgHierarchy& R, const SellPattern& G, con
                      R.t_cbase, R.t_ptr16, R.t_col16};
     R.top_vals = R.t_vals;
     R.top_dinv = R.t_dinv;
+    R.top_bytes = sell_bytes(G.slots, (int64_t)G.col16.size(), G.nslice, 4);
     return hipSuccess;
 }
 
@@ -199,6 +201,7 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
         AmgXfer& X = H.xf[l];
         X.n_fine = LP.n_fine; X.n_coarse = LP.n_coarse; X.n_coarse_cols = LP.n_coarse_cols; X.dense = LP.dense;
         X.onto_global = LP.onto_global;
+        X.n_glist = (int64_t)LP.glist.size();
         if ((e = upload(c, &X.agg, LP.agg)) != hipSuccess) return e;
         if ((e = upload(c, &X.members, LP.members)) != hipSuccess) return e;
         if ((e = upload(c, &X.gptr, LP.gptr)) != hipSuccess) return e;
@@ -239,7 +242,8 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
             // top level of a replicated hierarchy (`top`), which is a coarse level of the whole cycle
             if (l >= 1 && have_prev && (e = upload_sweep_plan(c, Aprev, LP.AP, H.sw[l])) != hipSuccess) return e;
             if (l == 0 && top && (e = upload_sweep_plan(c, *top, LP.AP, H.sw[0])) != hipSuccess) return e;
-            X.with_ap = true; X.ap_nslice = LP.AP.nslice; X.ap_slots = LP.AP.slots;
+            X.with_ap = true; X.ap_nslice = LP.AP.nslice; X.ap_slots = LP.AP.slots; X.ap_slots16 = (int64_t)LP.AP.col16.size();
+            X.ap_n_glist = (int64_t)LP.ap_glist.size();
             if (l == 0) H.ap_nnz0 = LP.AP.nnz;
             if ((e = upload(c, &X.ap_ptr, LP.AP.ptr)) != hipSuccess) return e;
             if ((e = upload(c, &X.ap_col, LP.AP.col)) != hipSuccess) return e;
@@ -266,6 +270,7 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
             if (l + 1 >= nx) return hipErrorInvalidValue;  // a hierarchy must end on a dense level
             AmgLevel& L = H.lv[l + 1];
             L.n = LP.Ac.n_rows; L.n_cols = LP.Ac.n_cols; L.nslice = LP.Ac.nslice; L.slots = LP.Ac.slots;
+            L.slots16 = (int64_t)LP.Ac.col16.size();
             if ((e = upload(c, &L.ptr, LP.Ac.ptr)) != hipSuccess) return e;
             if ((e = upload(c, &L.col, LP.Ac.col)) != hipSuccess) return e;
             if ((e = upload(c, &L.rowlen, LP.Ac.rowlen)) != hipSuccess) return e;
@@ -384,6 +389,11 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
     c->nblk = (int)P.blk_slice0.size() - 1;
     c->cells_staged = (int64_t)P.blk_cells.size();
     c->grid = (int)std::min<int64_t>(kMaxParts, std::max<int64_t>(1, (c->n_own + kBlock - 1) / kBlock));
+    c->slots16 = (int64_t)P.A.col16.size();
+    // one assembly pass: block descriptors, halo lists, staged cells (8 B), incidence lists, one plan word per slot, the
+    // 13 nodal doubles + Dirichlet flag of every own row (halo gathers are re-reads), and F, 1/diag, the values
+    c->asm_bytes = 4.0 * (double)(P.blk_desc.size() + P.blk_halo.size() + P.incptr.size()) + 2.0 * (double)(P.blk_cellv.size() + P.inccode.size())
+                   + 4.0 * (double)P.A.slots + 105.0 * (double)c->n_own + 16.0 * (double)c->n_own + 8.0 * (double)P.A.slots;
     c->np = c->grid;
     c->warm_its = std::max(1, std::min(T.warm_its, (int)Ctx::kWarmIts));   // experiments
     if (P.verts_max > kAsmVertsMax) { delete c; return fail("an assembly block touches more than 768 vertices (degenerate mesh?)"); }
@@ -1067,6 +1077,19 @@ int shk_comm_set_timing_only(shk_ctx* ctx, int32_t on) {
     return 0;
 }
 
+int shk_comm_allreduce_check(shk_ctx* ctx, double* value) {
+    CHECK_CTX(ctx);
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!value) return fail("null value");
+    HIPCHK(hipSetDevice(c->device));
+    double* d = c->d_io;   // staging vector, free between calls
+    HIPCHK(hipMemcpyAsync(d, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(allreduce_buffer(c, d, d, 1));
+    HIPCHK(hipMemcpyAsync(value, d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    WAITCHK(c);
+    return 0;
+}
+
 int shk_comm_mark_stalled(shk_ctx* ctx) {
     CHECK_CTX(ctx);
     reinterpret_cast<Ctx*>(ctx)->poisoned = true;
@@ -1130,6 +1153,7 @@ int shk_profile_enable(shk_ctx* ctx, int32_t on) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     WAITCHK(c);
     c->profiling = on != 0;
+    c->pending_bytes = 0.0;
     return 0;
 }
 
@@ -1144,6 +1168,7 @@ int shk_profile_read(shk_ctx* ctx, shk_profile* out, int32_t reset) {
         if (ms < 0.003f) continue;   // a launch that returned at once behind a solver's stop flag (~1 us)
         c->prof.ms[c->ev_pool[i].phase] += ms;
         c->prof.launches[c->ev_pool[i].phase] += 1;
+        c->prof.bytes[c->ev_pool[i].phase] += c->ev_pool[i].bytes;
     }
     c->ev_used = 0;
     if (out) *out = c->prof;

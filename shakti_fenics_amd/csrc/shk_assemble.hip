@@ -443,6 +443,7 @@ void launch_assemble(Ctx* c, double dt) {
     // host-side check of what the kernel's fixed loop counts assume (a violation would write outside its LDS)
     if (a.cells_max > kAsmCellsMax || a.verts_max > kAsmVertsMax) { set_error("assembly plan exceeds the kernel's staging limits"); return; }
     const bool builtin = a.quad.nq == 15 && a.qpoly.nq == 7;
+    note_bytes(c, c->asm_bytes);
     if (builtin) launch_phase(c, SHK_PH_ASSEMBLE, k_assemble<kBlock, 15, 7>, dim3(c->nblk), dim3(kBlock), c->asm_lds, a);
     else launch_phase(c, SHK_PH_ASSEMBLE, k_assemble<kBlock, 0, 0>, dim3(c->nblk), dim3(kBlock), c->asm_lds, a);
 }

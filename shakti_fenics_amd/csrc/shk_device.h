@@ -310,7 +310,7 @@ constexpr int kAmgSlotBytes = 8;   // float value + (mostly 16-bit) column
 // Multigrid hierarchy on the device (shk_amg.hip).  Level 0 is the Jacobian itself (Ctx::d_vals, d_dinv).
 struct AmgLevel {
     int32_t n = 0, n_cols = 0, nslice = 0;
-    int64_t slots = 0;
+    int64_t slots = 0, slots16 = 0;   // stored slots; of them with 16-bit columns
     int32_t *ptr = nullptr, *col = nullptr, *diag_slot = nullptr, *cbase = nullptr, *ptr16 = nullptr;
     uint16_t* col16 = nullptr;
     uint8_t* rowlen = nullptr;
@@ -325,7 +325,8 @@ struct AmgXfer {  // level l -> l+1
     // A*P of the fine level (optional): thinner operator for the first smoothing sweep after the prolongation
     bool with_ap = false;
     int32_t ap_nslice = 0;
-    int64_t ap_slots = 0;
+    int64_t ap_slots = 0, ap_slots16 = 0;
+    int64_t n_glist = 0, ap_n_glist = 0;   // entries of the Galerkin gather lists (byte accounting of the refresh)
     int32_t *ap_ptr = nullptr, *ap_col = nullptr, *ap_cbase = nullptr, *ap_ptr16 = nullptr, *ap_gptr = nullptr,
             *ap_glist = nullptr;
     uint16_t* ap_col16 = nullptr;
@@ -340,6 +341,7 @@ struct DevSweepPlan {
     int32_t nblk = 0, width = 0, max_local = 0;
     int32_t *hdr = nullptr, *ext_info = nullptr;
     uint16_t *lcol_own = nullptr, *ring_lcol = nullptr;
+    double plan_bytes = 0;   // bytes of the plan arrays one launch streams (byte accounting)
     bool ready() const { return nblk > 0; }
 };
 // A hierarchy is either block-local (the owned diagonal block of a subdomain, or the whole matrix of a single
@@ -350,6 +352,7 @@ struct AmgHierarchy {
     // (bound by amg_bind_top before use), or the gathered global level of a replicated coarse hierarchy.
     DevSell topA{};
     const float *top_vals = nullptr, *top_dinv = nullptr;
+    double top_bytes = 0.0;      // bytes one sweep streams of the top operator (byte accounting)
     std::vector<AmgLevel> lv;    // [0] unused, [l] = sparse coarse level l
     std::vector<AmgXfer> xf;     // [l] : level l -> l+1; the last one lands on the dense coarsest level
     std::vector<int> plan_of;    // distributed: index into Comm::plans of level l's halo plan (size = xf.size())
@@ -533,7 +536,10 @@ struct Ctx {
                              // shk_destroy must neither synchronise nor free (both would block for ever)
     // profiling
     bool profiling = false;
-    struct Ev { hipEvent_t a, b; int phase; };
+    struct Ev { hipEvent_t a, b; int phase; double bytes; };
+    double pending_bytes = 0.0;   // note_bytes() of the launches about to be timed
+    double asm_bytes = 0.0;       // what one assembly pass streams (plan arrays + fields + outputs)
+    int64_t slots16 = 0;          // SELL slots of the Jacobian with 16-bit columns
     std::vector<Ev> ev_pool;
     size_t ev_used = 0;
     shk_profile prof{};
@@ -623,6 +629,12 @@ hipError_t amg_upload_rep_top(Ctx* c, AmgHierarchy& R, const SellPattern& G, con
 hipError_t allreduce_parts(Ctx* c, int first, int nslots);
 hipError_t allreduce_part_arrays(Ctx* c, const double* part, double* red, int nslots);   // any partial arrays -> scalars
 
+// Byte accounting of the profiled launches (shk_profile.bytes): a launch site notes what its kernel has to move BEFORE
+// it launches (launch_phase) or inside the PhaseTimer scope that times it.
+inline void note_bytes(Ctx* c, double bytes) { if (c->profiling) c->pending_bytes += bytes; }
+inline double sell_bytes(int64_t slots, int64_t slots16, int64_t nslice, int value_bytes) {
+    return (double)slots * value_bytes + 2.0 * (double)slots16 + 4.0 * (double)(slots - slots16) + 16.0 * (double)nslice;
+}
 struct PhaseTimer {  // RAII hipEvent pair when profiling is on
     Ctx* c;
     int idx = -1;

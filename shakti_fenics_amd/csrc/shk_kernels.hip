@@ -60,6 +60,7 @@ __global__ __launch_bounds__(kBlock) void k_scale(int64_t slots, const int32_t* 
 
 void launch_scale(Ctx* c) {
     PhaseTimer t(c, SHK_PH_OTHER);
+    note_bytes(c, 20.0 * (double)c->slots + 8.0 * (double)c->n_own);
     int g = (int)std::min<int64_t>((c->slots + kBlock - 1) / kBlock, 8192);
     hipLaunchKernelGGL(k_scale, dim3(g), dim3(kBlock), 0, c->stream, c->slots, c->d_sell_col, c->d_vals, c->d_dinv,
                        c->d_vals_s);
@@ -139,7 +140,12 @@ static SpmvArgs spmv_args(Ctx* c, const double* vals, const void* x, double* y) 
     return a;
 }
 
+// bytes one Krylov product moves: the SELL stream, x (TX), y, and the dot-product operands of its mode
+static double spmv_bytes(const Ctx* c, int mode, int x_bytes) {
+    return sell_bytes(c->slots, c->slots16, c->plan.A.nslice, 8) + (double)c->n_own * (x_bytes + 8 + (mode == 1 ? 8 : mode == 2 ? 16 : 0));
+}
 void launch_spmv_plain(Ctx* c, const double* vals, const double* x, double* y) {
+    note_bytes(c, spmv_bytes(c, 0, 8));
     launch_phase(c, SHK_PH_SPMV, k_spmv<0, double>, dim3(c->grid), dim3(kBlock), 0, spmv_args(c, vals, x, y));
 }
 
@@ -216,6 +222,7 @@ __global__ __launch_bounds__(kBlock) void k_spmm(const SpmmArgs<M> a) {
 // y[j] = A x[j], j < m <= 4 (m = 3 runs the four-vector kernel with its last vector doubled)
 static void launch_spmm(Ctx* c, const double* vals, int m, double* const* x, double* const* y) {
     if (m == 1) { launch_spmv_plain(c, vals, x[0], y[0]); return; }
+    note_bytes(c, sell_bytes(c->slots, c->slots16, c->plan.A.nslice, 8) + 16.0 * (double)c->n_own * (m == 2 ? 2 : 4));
     if (m == 2) {
         SpmmArgs<2> a{c->sell(), vals, {x[0], x[1]}, {y[0], y[1]}};
         launch_phase(c, SHK_PH_VECTOR, k_spmm<2>, dim3(c->grid), dim3(kBlock), 0, a);   // (not the Krylov product's leg)
@@ -245,6 +252,7 @@ void launch_stream_read(Ctx* c) {
 
 void launch_norm2(Ctx* c, const double* x, double* partials) {
     PhaseTimer t(c, SHK_PH_OTHER);
+    note_bytes(c, 8.0 * (double)c->n_own);
     hipLaunchKernelGGL(k_norm2, dim3(c->grid), dim3(kBlock), 0, c->stream, c->n_own, x, partials);
 }
 
@@ -367,6 +375,7 @@ __global__ __launch_bounds__(kBlock) void k_bicg_u(int64_t n, int it, int np, in
 
 void krylov_init(Ctx* c, const double* rhs) {
     PhaseTimer t(c, SHK_PH_VECTOR);
+    note_bytes(c, 40.0 * (double)c->n_own);
     hipLaunchKernelGGL(k_bicg_init, dim3(c->grid), dim3(kBlock), 0, c->stream, c->n_own, rhs, c->d_r, c->d_rhat,
                        c->d_p, c->d_y, c->d_part, c->d_state);
 }
@@ -393,6 +402,7 @@ __global__ __launch_bounds__(kBlock) void k_true_residual(int64_t n, const doubl
 }
 void launch_accumulate(Ctx* c, bool first) {
     PhaseTimer t(c, SHK_PH_VECTOR);
+    note_bytes(c, (first ? 16.0 : 24.0) * (double)c->n_own);
     hipLaunchKernelGGL(k_accumulate, dim3(c->grid), dim3(kBlock), 0, c->stream, c->n_own, first ? 1 : 0, c->d_y,
                        c->d_ytot);
 }
@@ -516,6 +526,7 @@ hipError_t launch_warm_start(Ctx* c, int k) {   // d_ytot = the projected guess,
     launch_spmm(c, A, a.m, c->d_guess[k], images);
     {
         PhaseTimer t(c, SHK_PH_VECTOR);
+        note_bytes(c, 8.0 * (a.m + 1) * (double)c->n_own);
         hipLaunchKernelGGL(k_warm_dots, dim3(c->grid), dim3(kBlock), 0, c->stream, a);
     }
     // one subdomain: the consumers sum the partial arrays themselves; several: fixed-order local sums, one all-reduce
@@ -525,6 +536,7 @@ hipError_t launch_warm_start(Ctx* c, int k) {   // d_ytot = the projected guess,
         a.red = c->d_red_w; a.np = 1; a.rs = 1;
     }
     PhaseTimer t(c, SHK_PH_VECTOR);
+    note_bytes(c, 8.0 * (2 * a.m + 3) * (double)c->n_own);
     hipLaunchKernelGGL(k_warm_apply, dim3(c->grid), dim3(kBlock), 0, c->stream, a);
     return hipSuccess;
 }
@@ -536,6 +548,7 @@ static void launch_spmv_boundary(Ctx* c, SpmvArgs a) {
     if (c->n_bslices <= 0) return;
     a.part = c->d_part_b;
     PhaseTimer t(c, SHK_PH_HALO);
+    note_bytes(c, 12.0 * 64.0 * 8.0 * (double)c->n_bslices);   // ~8 entries per row of the flagged slices
     hipLaunchKernelGGL((k_spmv<MODE, TX, 2>), dim3(std::min((c->n_bslices + 3) / 4, kMaxParts)), dim3(kBlock), 0, c->stream, a);
 }
 
@@ -545,6 +558,7 @@ hipError_t launch_true_residual(Ctx* c) {  // d_rhs = F - A' ytot, partials in P
     if (c->overlap) {
         if ((e = hipEventRecord(c->ev_ready, c->stream)) != hipSuccess) return e;
         const SpmvArgs a = spmv_args(c, A, c->d_ytot, c->d_t);
+        note_bytes(c, spmv_bytes(c, 0, 8));
         launch_phase(c, SHK_PH_SPMV, k_spmv<0, double, 1>, dim3(c->grid), dim3(kBlock), 0, a);
         if ((e = halo_begin(c, c->d_ytot)) != hipSuccess) return e;
         if ((e = halo_end(c)) != hipSuccess) return e;
@@ -554,6 +568,7 @@ hipError_t launch_true_residual(Ctx* c) {  // d_rhs = F - A' ytot, partials in P
         launch_spmv_plain(c, A, c->d_ytot, c->d_t);
     }
     PhaseTimer t(c, SHK_PH_VECTOR);
+    note_bytes(c, 24.0 * (double)c->n_own);
     hipLaunchKernelGGL(k_true_residual, dim3(c->grid), dim3(kBlock), 0, c->stream, c->n_own, c->d_F, c->d_t,
                        c->d_rhs, c->d_part + P_AUX * kMaxParts);
     return allreduce_parts(c, P_AUX, 1);
@@ -570,6 +585,7 @@ static hipError_t krylov_product(Ctx* c, const double* A, const void* x, double*
     hipError_t e;
     if (c->overlap) {
         if ((e = hipEventRecord(c->ev_ready, c->stream)) != hipSuccess) return e;
+        note_bytes(c, spmv_bytes(c, MODE, amg ? 4 : 8));
         if (amg) launch_phase(c, SHK_PH_SPMV, k_spmv<MODE, float, 1>, g, b, 0, a);
         else launch_phase(c, SHK_PH_SPMV, k_spmv<MODE, double, 1>, g, b, 0, a);
         if ((e = amg ? halo_begin_f32(c, (float*)const_cast<void*>(x)) : halo_begin(c, (double*)const_cast<void*>(x))) != hipSuccess) return e;
@@ -580,9 +596,11 @@ static hipError_t krylov_product(Ctx* c, const double* A, const void* x, double*
     }
     if (amg) {
         if (!c->comm.plans.empty() && (e = halo_exchange_plan_f32(c, c->comm.plans[0], (float*)const_cast<void*>(x))) != hipSuccess) return e;
+        note_bytes(c, spmv_bytes(c, MODE, 4));
         launch_phase(c, SHK_PH_SPMV, k_spmv<MODE, float>, g, b, 0, a);
     } else {
         if ((e = halo_exchange(c, (double*)const_cast<void*>(x))) != hipSuccess) return e;
+        note_bytes(c, spmv_bytes(c, MODE, 8));
         launch_phase(c, SHK_PH_SPMV, k_spmv<MODE, double>, g, b, 0, a);
     }
     return hipSuccess;
@@ -601,6 +619,7 @@ hipError_t krylov_iteration(Ctx* c, int it) {
     if ((e = allreduce_parts(c, P_RR, 2)) != hipSuccess) return e;
     {
         PhaseTimer t(c, SHK_PH_VECTOR);
+        note_bytes(c, 32.0 * (double)c->n_own);
         hipLaunchKernelGGL(k_bicg_s, g, b, 0, c->stream, c->n_own, it, c->params.krylov_max_it, c->cur_rtol2,
                            c->cur_atol2, c->np, c->red_stride, c->d_red, part, c->d_r, c->d_v, c->d_rhat, c->d_s, c->d_state);
     }
@@ -609,6 +628,7 @@ hipError_t krylov_iteration(Ctx* c, int it) {
     if ((e = allreduce_parts(c, P_TS, 4)) != hipSuccess) return e;
     {
         PhaseTimer t(c, SHK_PH_VECTOR);
+        note_bytes(c, (amg ? 72.0 : 64.0) * (double)c->n_own);
         if (amg)
             hipLaunchKernelGGL(k_bicg_u<float>, g, b, 0, c->stream, c->n_own, it, c->np, c->red_stride, c->d_red, part, c->d_s, c->d_t, c->d_v,
                                c->d_p, (const float*)c->d_phat, (const float*)c->d_shat, c->d_y, c->d_r, c->d_state);
@@ -633,6 +653,7 @@ __global__ __launch_bounds__(kBlock) void k_newton_update(int64_t n, double rela
 
 void launch_newton_update(Ctx* c, bool apply) {
     PhaseTimer t(c, SHK_PH_OTHER);
+    note_bytes(c, (apply ? 32.0 : 16.0) * (double)c->n_own + (c->use_amg ? 0.0 : 8.0 * (double)c->n_own));
     hipLaunchKernelGGL(k_newton_update, dim3(c->grid), dim3(kBlock), 0, c->stream, c->n_own, c->params.newton_relax,
                        apply ? 1 : 0, c->use_amg ? 0 : 1, c->d_ytot, c->d_dinv, c->f[SHK_DX], c->f[SHK_N]);
 }
@@ -724,12 +745,15 @@ hipError_t launch_update_explicit(Ctx* c, double dt) {
     int g = (int)std::min<int64_t>((c->n_own + kBlock - 1) / kBlock, 4096);
     {
         PhaseTimer t(c, SHK_PH_UPDATE);
+        // per vertex: last cell + its three ids, coordinates, z_b z_s N b melt_n G qx qy in; qx qy melt m0 out
+        note_bytes(c, (4.0 + 12.0 + 16.0 + 64.0 + 32.0) * (double)c->n_own);
         hipLaunchKernelGGL(k_update_a, dim3(g), dim3(kBlock), 0, c->stream, a);
     }
     hipError_t e = halo_exchange(c, c->d_melt_tmp);  // neighbours' new melt rate enters grad(melt_n) below
     if (e != hipSuccess) return e;
     {
         PhaseTimer t(c, SHK_PH_UPDATE);
+        note_bytes(c, (4.0 + 12.0 + 16.0 + 32.0 + 16.0) * (double)c->n_own);
         hipLaunchKernelGGL(k_update_b, dim3(g), dim3(kBlock), 0, c->stream, a);
     }
     std::swap(c->f[SHK_MELT_N], c->d_melt_tmp);
@@ -797,6 +821,8 @@ int profile_slot(Ctx* c, int phase) {
     }
     const int idx = (int)c->ev_used++;
     c->ev_pool[idx].phase = phase;
+    c->ev_pool[idx].bytes = c->pending_bytes;   // noted by the launch site (launch_phase); a PhaseTimer adds at its end
+    c->pending_bytes = 0.0;
     return idx;
 }
 PhaseTimer::PhaseTimer(Ctx* c_, int phase) : c(c_) {
@@ -805,7 +831,10 @@ PhaseTimer::PhaseTimer(Ctx* c_, int phase) : c(c_) {
     (void)hipEventRecord(c->ev_pool[idx].a, c->stream);
 }
 PhaseTimer::~PhaseTimer() {
-    if (idx >= 0) (void)hipEventRecord(c->ev_pool[idx].b, c->stream);
+    if (idx < 0) return;
+    (void)hipEventRecord(c->ev_pool[idx].b, c->stream);
+    c->ev_pool[idx].bytes += c->pending_bytes;   // what the launches inside the scope noted
+    c->pending_bytes = 0.0;
 }
 
 }  // namespace shk

@@ -763,7 +763,7 @@ std::string build_sweep_plan(const SellPattern& A, const SellPattern& AP, SweepP
         for (int k = 0; k < A.rowlen[i]; ++k) f(k, A.col[base + k * kSlice + l]);
     };
     for (int32_t b = 0; b < nblk; ++b) {
-        const int32_t r0 = b * kSweepRows, r1 = std::min(n, r0 + kSweepRows), n0 = r1 - r0;
+        const int32_t r0 = b * kSweepRows, r1 = std::min(n, r0 + kSweepRows);
         for (auto& v : ring) v.clear();
         fixed.clear();
         for (int32_t i = r0; i < r1; ++i) { stamp[i] = b; lid[i] = i - r0; }

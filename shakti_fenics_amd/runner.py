@@ -8,7 +8,7 @@ import numpy as np
 from . import _lib
 from .bc import locate_boundary_dofs
 from .mesh import basin_mesh, rectangle_mesh
-from .synthetic import CONFIGS, N_BDRY, outflow_predicate, synthetic_fields
+from .synthetic import BASIN_CONFIGS, CONFIGS, N_BDRY, config_mesh, outflow_predicate, synthetic_fields
 
 
 KERNEL_SOURCES = ("shk_device.h", "shk_kernels.hip", "shk_assemble.hip", "shk_amg.hip", "shk_plan.cpp", "shk_plan.h")
@@ -53,16 +53,23 @@ def _pmc_traffic(config, nv):
         out["spmv"] = 0.5 * (k["spmv1"]["hbm_bytes"] + k["spmv2"]["hbm_bytes"])
     if "assemble" in k:
         out["assemble"] = k["assemble"]["hbm_bytes"]
+        out["assemble_valu_insts"] = k["assemble"].get("valu_wave_insts")
+        out["assemble_wait_any_frac"] = k["assemble"].get("wait_any_frac")
     return out
 
 
 class SingleRunner:
     def __init__(self, config="c4_10m", order="morton", dt=3600.0, storage=False, moulins=0, device=0,
                  krylov_rtol=1e-10, shape=None, precond="amg", basin=0):
-        nx, ny, Lx, Ly = CONFIGS[config] if shape is None else shape
         self.config_name = config if shape is None and not basin else None
-        # basin=n: the unstructured Delaunay basin mesh of ~n vertices (mesh.basin_mesh) instead of the rectangle
-        self.dom = basin_mesh(basin, order="random") if basin else rectangle_mesh(nx, ny, Lx, Ly, order=order)
+        # basin=n: the unstructured Delaunay basin mesh of ~n vertices (mesh.basin_mesh) instead of the rectangle;
+        # config "basin_*": the same kind of mesh on the bench footprint (synthetic.BASIN_CONFIGS)
+        if shape is None and not basin and config in BASIN_CONFIGS:
+            self.dom = config_mesh(config)
+            basin, (nx, ny, Lx, Ly) = self.dom.num_vertices, (0, 0) + BASIN_CONFIGS[config][1:]
+        else:
+            nx, ny, Lx, Ly = CONFIGS[config] if shape is None else shape
+            self.dom = basin_mesh(basin, order="random") if basin else rectangle_mesh(nx, ny, Lx, Ly, order=order)
         self._outflow = (lambda X: X[0] < 1e-9) if basin else outflow_predicate(self.dom)
         self.dt = dt
         sf = synthetic_fields(self.dom, storage_on=storage, moulins=moulins)
@@ -82,7 +89,8 @@ class SingleRunner:
         st = c.plan_stats()
         self.nv_global, self.ne_global, self.nnz_global = st["nv"], st["ne"], st["nnz"]
         self.stats = st
-        mesh_txt = (f"Delaunay basin mesh of {self.dom.num_vertices} vertices (hole, curved outlet, random order)" if basin else
+        mesh_txt = (f"Delaunay basin mesh of {self.dom.num_vertices} vertices (graded, hole, curved outlet, valence-13 stars, random "
+                    f"vertex order), rows up to {st['max_row_len']} entries" if basin else
                     f"{Lx/1e3:.0f} km x {Ly/1e3:.0f} km rectangle, {nx}x{ny} jittered P1 mesh ({order} order)")
         self._desc = (f"{mesh_txt}, dt {dt:g} s (first step 0.1 dt), storage {'on' if storage else 'off'}, {moulins} moulins, "
                       f"Dirichlet N = {N_BDRY:g} Pa on x = 0; |b_init| for the reference's signed draw (DESIGN.md section 1)")
@@ -111,103 +119,125 @@ class SingleRunner:
         self.ctx.sync()
 
     def roofline(self, peak_gbs: float) -> dict:
-        """Per-launch hipEvent timing of one more step on the library's stream.  The dominant kernel is the
-        SELL-64 SpMV in its two guises: `k_spmv` (2 launches per BiCGStab iteration) and, with the multigrid
-        preconditioner, the finest-level smoother `k_amg_post<true>` (4 launches per iteration)."""
+        """Per-launch hipEvent timing of one more step on the library's stream (events ride on the dispatch packets).
+        Headline = the dominant kernel, the SELL-64 SpMV `k_spmv<1|2>`, priced with the bytes it HAS to move (padded
+        slots, 16-bit columns, float x: shk_profile.bytes, accounted by the library per launch); SURVEY.md 8d's
+        algorithmic figure (fp64 values, int32 columns, double x) stands beside it.  `step` = every launch of the profiled
+        step: needed bytes over kernel time = whole-step HBM utilisation.  The assembly is graded against the ceiling that
+        binds it (fp64 VALU issue, from the committed counter file) as well as against HBM."""
         c = self.ctx
         c.profile_enable(True)
         c.profile_read(reset=True)
+        import time
+        c.sync()
+        t0 = time.perf_counter()
         info = self.step()
+        c.sync()
+        wall_ms = 1e3 * (time.perf_counter() - t0)
         prof = c.profile_read(reset=True)
         c.profile_enable(False)
         nv, nnz, slices = self.nv_global, self.nnz_global, (self.nv_global + 63) // 64
-        # algorithmic bytes per launch (fp64 values, int32 indices), SURVEY.md 8d
-        b_spmv = 12 * nnz + 4 * (nv + 1) + 16 * nv                      # values, colidx, rowptr, x, y = 104 nv
-        # multigrid smoother: float values + int32 indices; x (float), r (double), 1/diag (float), x' (float)
-        b_post = 8 * nnz + 4 * (slices + 1) + 20 * nv                   # x' = x + w D^-1 (r - A x)
-        b_asm = 12 * self.ne_global + 16 * nv + 88 * nv + 8 * nv + 8 * nnz  # 192 nv
-
+        ph = {k: v for k, v in prof.items() if k in _lib.PHASES}   # (prof also carries the aggregate "amg_coarse")
+        # SURVEY.md 8d's algorithmic bytes per launch (fp64 values, int32 indices)
+        alg = {"spmv": 12 * nnz + 4 * (nv + 1) + 16 * nv,                          # 104 nv
+               "assemble": 12 * self.ne_global + 16 * nv + 88 * nv + 8 * nv + 8 * nnz,  # 192 nv
+               "amg_fine": 8 * nnz + 4 * (slices + 1) + 20 * nv,                   # float values + int32 indices + 5 vectors
+               "amg_first": 8 * c.plan_stats()["ap_nnz"] + 4 * (slices + 1) + 21 * nv}
+        names = {"spmv": "k_spmv<1|2> (SELL-64 SpMV + fused BiCGStab dots)", "assemble": "k_assemble (fused residual + Jacobian)",
+                 "amg_fine": "k_amg_post<true> (finest-level multigrid smoother, SELL-64 SpMV)",
+                 "amg_first": "k_amg_first<true> (first sweep on the A*P operator)"}
         pmc = _pmc_traffic(getattr(self, "config_name", None), nv)
 
-        def leg(phase, nbytes, name):
-            n = max(prof[phase]["launches"], 1)
-            ms = prof[phase]["ms"] / n
-            ach = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            return {"kernel": name, "avg_launch_ms": ms, "launches": prof[phase]["launches"],
-                    "bytes_per_launch": nbytes, "achieved": ach, "frac": ach / peak_gbs,
+        def leg(phase):
+            n = max(ph[phase]["launches"], 1)
+            ms = ph[phase]["ms"] / n
+            need = ph[phase]["bytes"] / n
+            ach = need / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            ach_alg = alg[phase] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            return {"kernel": names[phase], "avg_launch_ms": ms, "launches": ph[phase]["launches"],
+                    "bytes_per_launch": need, "achieved": ach, "frac": ach / peak_gbs,
+                    "algorithmic": {"bytes_per_launch": alg[phase], "achieved": ach_alg, "frac": ach_alg / peak_gbs,
+                                    "note": "SURVEY.md 8d's figure (fp64 values, int32 columns, double x): bytes this "
+                                            "implementation does not all move"},
                     "traffic": pmc.get(phase)}
 
-        legs = {"spmv": leg("spmv", b_spmv, "k_spmv<1|2> (SELL-64 SpMV + fused BiCGStab dots)"),
-                "assemble": leg("assemble", b_asm, "k_assemble (fused residual + Jacobian)")}
-        # what the SpMV actually has to move: fp64 values, 16-bit column offsets on the slices that allow them (the plan
-        # reports the padded slot count), the float x of the multigrid cycle, y and the two dot operands in double
-        slots = self.stats["sell_slots"]
-        legs["spmv"]["needed_bytes"] = 8 * slots + 2 * slots + 16 * ((nv + 63) // 64) + 4 * nv + 8 * nv + 12 * nv
-        legs["spmv"]["needed_note"] = ("bytes this implementation must move per launch (padded SELL slots, 16-bit columns, float "
-                                       "x, double y and dot operands); `bytes_per_launch` is SURVEY.md 8d's algorithmic figure "
-                                       "(int32 columns, double x) that `achieved` is priced with")
-        legs["spmv"]["achieved_needed"] = legs["spmv"]["needed_bytes"] / (legs["spmv"]["avg_launch_ms"] * 1e-3) / 1e9 \
-            if legs["spmv"]["avg_launch_ms"] > 0 else 0.0
-        if prof["amg_fine"]["launches"]:
-            legs["amg_fine"] = leg("amg_fine", b_post, "k_amg_post<true> (finest-level multigrid smoother, SELL-64 SpMV)")
-        if prof.get("amg_first", {}).get("launches"):
-            ap = c.plan_stats()["ap_nnz"]
-            b_first = 8 * ap + 4 * (slices + 1) + 4 * nv + 16 * nv + 1 * nv    # A*P (float), agg, r / 1/diag / x', e
-            legs["amg_first"] = leg("amg_first", b_first, "k_amg_first<true> (first sweep on the A*P operator)")
-        dom = max((k for k in legs if k != "assemble"), key=lambda k: prof[k]["ms"])
+        legs = {k: leg(k) for k in ("spmv", "assemble", "amg_fine", "amg_first") if ph[k]["launches"]}
+        if "assemble" in legs:
+            a = legs["assemble"]
+            valu = pmc.get("assemble_valu_insts")
+            floor_ms = valu * 4.0 / (1024 * 2.4e9) * 1e3 if valu else None   # 4 cycles per fp64 wave-instruction, 1024 SIMDs
+            a.update(bound="fp64 valu", hbm_frac=a["frac"], valu_wave_insts=valu, valu_issue_floor_ms=floor_ms,
+                     frac=(floor_ms / a["avg_launch_ms"]) if floor_ms else None,
+                     bound_note="k_assemble is bound by fp64 vector issue, not HBM: frac = (VALU wave-instructions x 4 cycles / "
+                                "(1024 SIMDs x 2.4 GHz)) / measured time; hbm_frac = needed bytes / time / 8 TB/s"
+                                + ("" if floor_ms else " (no counter file for these kernel sources: frac is null)"))
+        dom = max((k for k in legs if k != "assemble"), key=lambda k: ph[k]["ms"])
         d = legs[dom]
-        # The same SpMV launched 20 times back to back between ONE event pair: what a launch takes without the
-        # dispatch latency that a per-launch event pair adds (this is the figure the rocprofv3 trace agrees with).
+        # whole step: every launch the profiled step made
+        tot_ms = sum(v["ms"] for v in ph.values())
+        tot_b = sum(v["bytes"] for v in ph.values())
+        step = {"definition": "needed bytes of EVERY launch of the profiled step (shk_profile.bytes) / their summed hipEvent "
+                              "durations / peak: whole-step HBM utilisation while a kernel runs; wall_ms adds launch gaps "
+                              "and host synchronisations",
+                "bytes": tot_b, "kernel_ms": tot_ms, "wall_ms": wall_ms,
+                "achieved": tot_b / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0,
+                "achieved_wall": tot_b / (wall_ms * 1e-3) / 1e9 if wall_ms > 0 else 0.0}
+        step["frac"] = step["achieved"] / peak_gbs
+        step["frac_wall"] = step["achieved_wall"] / peak_gbs
+        phase_gbs = {k: (v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0) for k, v in ph.items() if v["launches"]}
+        cycles = max(2 * info.krylov_its, 1)
+        levels = {k: {"ms_per_cycle": ph[k]["ms"] / cycles, "launches_per_cycle": ph[k]["launches"] / cycles,
+                      "gbs": phase_gbs.get(k, 0.0)}
+                  for k in _lib.COARSE_PHASES if ph[k]["launches"]}
+        # The same SpMV launched 20 times back to back between ONE event pair (cross-check of the per-launch events)
         c.assemble(self.dt)
         b2b_ms = c.time_kernel("spmv", 20)
-        b2b = {"kernel": "k_spmv<0> (same product without the fused dots), 20 launches between one hipEvent pair",
-                      "avg_launch_ms": b2b_ms, "bytes_per_launch": b_spmv,
-                      "achieved": b_spmv / (b2b_ms * 1e-3) / 1e9, "frac": b_spmv / (b2b_ms * 1e-3) / 1e9 / peak_gbs}
-        # north_star states its target on the "assembly + SpMV inner loop": both kernels' algorithmic bytes over
-        # both kernels' time in the profiled step
-        t_in = prof["assemble"]["ms"] + prof["spmv"]["ms"]
-        by_in = b_asm * prof["assemble"]["launches"] + b_spmv * prof["spmv"]["launches"]
-        inner = {"definition": "algorithmic bytes of all k_assemble + k_spmv launches of the profiled step / their summed "
-                               "hipEvent durations", "achieved": by_in / (t_in * 1e-3) / 1e9 if t_in > 0 else 0.0,
-                 "launches": {"assemble": prof["assemble"]["launches"], "spmv": prof["spmv"]["launches"]},
-                 "note": "a mix figure: the assembly runs at ~13 % and the product at ~75-85 % of the roofline, so the aggregate "
-                         "falls as a step needs fewer Krylov iterations per assembly (round 1: 92 iterations in the profiled "
-                         "step, now ~26-34)"}
-        inner["frac"] = inner["achieved"] / peak_gbs
-        # the same mix of launches priced with back-to-back durations (no per-launch event overhead)
-        asm_b2b = c.time_kernel("assemble", 3, self.dt)
-        t_b2b = asm_b2b * prof["assemble"]["launches"] + b2b_ms * prof["spmv"]["launches"]
-        inner["back_to_back"] = {"assemble_ms": asm_b2b, "spmv_ms": b2b_ms,
-                                 "achieved": by_in / (t_b2b * 1e-3) / 1e9 if t_b2b > 0 else 0.0}
-        inner["back_to_back"]["frac"] = inner["back_to_back"]["achieved"] / peak_gbs
-        # SURVEY.md 8d also asks for a whole Krylov iteration and a whole Newton iteration against the roofline, priced with
-        # ITS algorithmic bytes -- those of the textbook Jacobi-BiCGStab iteration (416 Nv) and of a Newton iteration with
-        # k such iterations ((224 + 416 k) Nv).  The multigrid-preconditioned iteration moves several times more (two cycles
-        # on top of the two products), so these fractions say how much time a Jacobi iteration's bytes would have been worth,
-        # not how busy the memory system was.
+        need_spmv = d["bytes_per_launch"] if dom == "spmv" else legs["spmv"]["bytes_per_launch"]
+        b2b = {"kernel": "k_spmv<0> (same product without the fused dots, double x), 20 launches between one hipEvent pair",
+               "avg_launch_ms": b2b_ms, "bytes_per_launch": alg["spmv"],
+               "achieved": alg["spmv"] / (b2b_ms * 1e-3) / 1e9, "frac": alg["spmv"] / (b2b_ms * 1e-3) / 1e9 / peak_gbs}
+        # north_star states its target on the "assembly + SpMV inner loop"
+        t_in = ph["assemble"]["ms"] + ph["spmv"]["ms"]
+        inner = {"definition": "all k_assemble + k_spmv launches of the profiled step: bytes / summed hipEvent durations",
+                 "needed": {"achieved": (ph["assemble"]["bytes"] + ph["spmv"]["bytes"]) / (t_in * 1e-3) / 1e9 if t_in > 0 else 0.0},
+                 "algorithmic": {"achieved": (alg["assemble"] * ph["assemble"]["launches"] + alg["spmv"] * ph["spmv"]["launches"])
+                                 / (t_in * 1e-3) / 1e9 if t_in > 0 else 0.0},
+                 "launches": {"assemble": ph["assemble"]["launches"], "spmv": ph["spmv"]["launches"]},
+                 "note": "a mix figure: the assembly is bound by fp64 issue (~14 % of the HBM roofline), the product runs at "
+                         "~75-80 %, so the aggregate falls as a step needs fewer Krylov iterations per assembly"}
+        for v in (inner["needed"], inner["algorithmic"]):
+            v["frac"] = v["achieved"] / peak_gbs
+        inner["achieved"], inner["frac"] = inner["needed"]["achieved"], inner["needed"]["frac"]
+        # SURVEY.md 8d: a whole Krylov / Newton iteration priced with the textbook Jacobi-BiCGStab bytes
         kits, nits = max(info.krylov_its, 1), max(info.newton_its, 1)
-        t_kry = sum(prof[k]["ms"] for k in ("spmv", "vector", "amg_fine", "amg_coarse", "amg_first", "halo") if k in prof)
-        t_all = sum(v["ms"] for v in prof.values())
+        t_kry = sum(ph[k]["ms"] for k in ph if k in ("spmv", "vector", "amg_fine", "amg_first", "halo") or k in _lib.COARSE_PHASES)
         whole = {
             "krylov_iteration": {"ms": t_kry / kits, "algorithmic_bytes": 416 * nv,
                                  "achieved": 416 * nv / (t_kry / kits * 1e-3) / 1e9 if t_kry > 0 else 0.0},
-            "newton_iteration": {"ms": t_all / nits, "krylov_its_per_newton": kits / nits,
+            "newton_iteration": {"ms": tot_ms / nits, "krylov_its_per_newton": kits / nits,
                                  "algorithmic_bytes": (224 + 416 * kits / nits) * nv,
-                                 "achieved": (224 + 416 * kits / nits) * nv / (t_all / nits * 1e-3) / 1e9 if t_all > 0 else 0.0},
+                                 "achieved": (224 + 416 * kits / nits) * nv / (tot_ms / nits * 1e-3) / 1e9 if tot_ms > 0 else 0.0},
             "note": "SURVEY.md 8d's algorithmic bytes of Jacobi-BiCGStab over the time of the multigrid-preconditioned "
-                    "iteration of the profiled step (summed per-phase hipEvent durations)"}
+                    "iteration of the profiled step (the multigrid iteration moves several times those bytes: see `step`)"}
         for v in (whole["krylov_iteration"], whole["newton_iteration"]):
             v["frac"] = v["achieved"] / peak_gbs
         return {
-            "whole_iterations": whole,
             "bound": "hbm", "kernel": d["kernel"], "achieved": d["achieved"], "peak": peak_gbs, "unit": "GB/s",
-            "frac": d["frac"], "traffic": d["traffic"], "bytes_per_launch": d["bytes_per_launch"],
-            "traffic_source": pmc.get("source"),
+            "frac": d["frac"], "bytes_per_launch": d["bytes_per_launch"],
+            "bytes_note": "bytes the kernel HAS to move per launch (padded SELL slots, 16-bit columns where the slice allows, "
+                          "float x of the multigrid cycle, double y and dot operands); `algorithmic` prices the same time with "
+                          "SURVEY.md 8d's figure",
+            "algorithmic": d["algorithmic"],
+            "traffic": d["traffic"], "traffic_source": pmc.get("source"),
             "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"],
             "kernels": legs,
+            "step": step,
+            "coarse_levels": levels,
+            "phase_ms": {k: v["ms"] for k, v in prof.items()},
+            "phase_gbs": phase_gbs,
+            "whole_iterations": whole,
             "spmv_back_to_back": b2b,
             "assembly_plus_spmv": inner,
-            "phase_ms": {k: v["ms"] for k, v in prof.items()},
             "profiled_step": {"newton_its": info.newton_its, "krylov_its": info.krylov_its},
         }
 
@@ -216,51 +246,61 @@ class SingleRunner:
 
 
 class PartitionedRunner(SingleRunner):
-    """Same workload, vertices split over `world` subdomains (one process / GPU each): every rank builds
-    the global synthetic mesh, keeps its subdomain and joins the communicator."""
+    """Same workload, vertices split over `world` subdomains (one process / GPU each).  The global synthetic mesh is
+    built, partitioned and cut ONCE, on rank 0, which leaves every rank's subdomain (mesh, halo plan, field slices,
+    Dirichlet dofs) as one .npz in a scratch directory of the node (bench.py runs on ONE node): the other ranks never
+    hold the 10M-vertex mesh (round 2: every rank generated and partitioned all of it, 17 s and several GB x world).
+    Before the first solve the data path is exercised once (distributed.startup_check)."""
 
     def __init__(self, rank, world, device, config="c4_10m", order="morton", dt=3600.0, storage=False,
                  moulins=0, krylov_rtol=1e-10, shape=None, transport="rccl", group=None, precond="amg", basin=0):
-        from .distributed import make_context
-        from .partition import partition
+        import torch
+        import torch.distributed as dist
+        from .distributed import make_context, scatter_subdomains, startup_check
 
-        nx, ny, Lx, Ly = CONFIGS[config] if shape is None else shape
-        dom = basin_mesh(basin, order="random") if basin else rectangle_mesh(nx, ny, Lx, Ly, order=order)
         self.dt = dt
-        sf = synthetic_fields(dom, storage_on=storage, moulins=moulins)
-        bc_global = locate_boundary_dofs(dom, (lambda X: X[0] < 1e-9) if basin else outflow_predicate(dom))
-        self.sub = sub = partition(dom, world, rank)
-        self.nv_global, self.ne_global = dom.num_vertices, dom.num_cells
-        g = sub.gid
+
+        def make_global():
+            nonlocal basin
+            if shape is None and not basin and config in BASIN_CONFIGS:
+                dom = config_mesh(config)
+                basin, (nx, ny, Lx, Ly) = dom.num_vertices, (0, 0) + BASIN_CONFIGS[config][1:]
+            else:
+                nx, ny, Lx, Ly = CONFIGS[config] if shape is None else shape
+                dom = basin_mesh(basin, order="random") if basin else rectangle_mesh(nx, ny, Lx, Ly, order=order)
+            sf = synthetic_fields(dom, storage_on=storage, moulins=moulins)
+            sf["b_init"] = np.abs(sf["b_init"])
+            bc_global = locate_boundary_dofs(dom, (lambda X: X[0] < 1e-9) if basin else outflow_predicate(dom))
+            mesh_txt = (f"Delaunay basin mesh of {dom.num_vertices} vertices (graded, hole, curved outlet, random order)" if basin else
+                        f"{Lx/1e3:.0f} km x {Ly/1e3:.0f} km rectangle, {nx}x{ny} jittered P1 mesh ({order} order)")
+            return dom, sf, bc_global, dict(mesh=mesh_txt)
+
+        self.sub, f, self.bc, info = scatter_subdomains(rank, world, make_global, group)
+        sub = self.sub
+        self.nv_global, self.ne_global = info["nv"], info["ne"]
+        self.device = device
         self.ctx = c = make_context(sub, device, transport, group)
+        self.wiring = startup_check(c, sub, group)   # one exchange + one all-reduce with value checks, before any solve
+        self.wiring["device"] = int(device)
         c.set_params(krylov_rtol=krylov_rtol, precond=_lib.PRECOND[precond])
-        c.set_field("z_b", sf["z_b"][g]); c.set_field("z_s", sf["z_s"][g]); c.set_field("G", sf["G"][g])
-        c.set_field("inputs", sf["inputs"][g]); c.set_field("storage", sf["lake_bdry"][g])
-        c.set_field("b", np.abs(sf["b_init"][g]))
-        c.set_field("N_n", sf["N_init"][g]); c.set_field("N", sf["N_init"][g])
-        c.set_field("q", sf["q_init"][g]); c.set_field("melt_n", np.zeros(sub.n_loc))
-        g2l = np.full(dom.num_vertices, -1, dtype=np.int64)
-        g2l[g] = np.arange(g.size)
-        loc = g2l[bc_global]
-        self.bc = loc[loc >= 0].astype(np.int32)
+        c.set_field("z_b", f["z_b"]); c.set_field("z_s", f["z_s"]); c.set_field("G", f["G"])
+        c.set_field("inputs", f["inputs"]); c.set_field("storage", f["lake_bdry"])
+        c.set_field("b", f["b_init"])
+        c.set_field("N_n", f["N_init"]); c.set_field("N", f["N_init"])
+        c.set_field("q", f["q_init"]); c.set_field("melt_n", np.zeros(sub.n_loc))
         c.set_dirichlet(self.bc, N_BDRY)
         self.stats = c.plan_stats()
         # nnz of the global matrix = sum over subdomains of the owned rows' entries
-        import torch
-        import torch.distributed as dist
         t = torch.tensor([self.stats["nnz"]], dtype=torch.int64)
         if dist.get_backend(group) == "nccl":
             t = t.cuda(device)
         dist.all_reduce(t, group=group)
         self.nnz_global = int(t.item())
         self.transport = transport
-        mesh_txt = (f"Delaunay basin mesh of {dom.num_vertices} vertices (hole, curved outlet, random order)" if basin else
-                    f"{Lx/1e3:.0f} km x {Ly/1e3:.0f} km rectangle, {nx}x{ny} jittered P1 mesh ({order} order)")
-        self._desc = (f"{mesh_txt}, dt {dt:g} s (first step 0.1 dt), storage {'on' if storage else 'off'}, {moulins} moulins, "
+        self._desc = (f"{info['mesh']}, dt {dt:g} s (first step 0.1 dt), storage {'on' if storage else 'off'}, {moulins} moulins, "
                       f"Dirichlet N = {N_BDRY:g} Pa on x = 0; |b_init| for the reference's signed draw; {world} subdomains (RCB), "
                       f"{transport} halo")
         self.next_step = 0
-        del dom, sf
 
     def roofline(self, peak_gbs: float) -> dict:
         # per-subdomain kernel: algorithmic bytes of THIS rank's SpMV launch

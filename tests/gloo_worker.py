@@ -29,8 +29,33 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     dom, f, bc, g = make_case(nx=37, ny=19, Lx=20e3, Ly=10e3, perturb=True)
     prm = O.Params()
-    sub = partition(dom, world, rank)
     exchange, allreduce = gloo_callbacks()
+
+    # (0) the start-up path of a multi-rank run (runner.PartitionedRunner / bench.py --gpus N): the mesh is built and cut on
+    # rank 0 only, every rank loads its subdomain from the node's scratch space, then one ghost exchange of global ids and
+    # one all-reduce of rank + 1 are checked -- here through the transport callables (HostOps), on a device through the
+    # context (ContextOps).  The subdomain that arrives must be the one this rank would have cut itself.
+    from shakti_fenics_amd import _lib
+    from shakti_fenics_amd.distributed import HostOps, scatter_subdomains, startup_check
+    fields = {k: v for k, v in f.__dict__.items()}
+    sub, mine, lbc0, info = scatter_subdomains(rank, world, lambda: (dom, fields, bc, dict(mesh="test")))
+    ref = partition(dom, world, rank)
+    for k in ("gid", "xy", "cells", "cell_gid", "nbr", "send_ptr", "send_idx", "recv_ptr"):
+        assert np.array_equal(getattr(sub, k), getattr(ref, k)), k
+    assert (sub.n_own, sub.n_ghost, info["nv"], info["ne"]) == (ref.n_own, ref.n_ghost, dom.num_vertices, dom.num_cells)
+    assert all(np.array_equal(mine[k], v[sub.gid]) for k, v in fields.items())
+    wiring = startup_check(HostOps(sub, exchange, allreduce), sub)
+    assert wiring["n_ghost"] == sub.n_ghost and sum(wiring["ghosts_per_neighbour"]) == sub.n_ghost
+    # ... and a transport that delivers one wrong ghost value on ONE rank fails the check on EVERY rank
+    def bad_exchange(nbr, send, sp, recv, rp):
+        exchange(nbr, send, sp, recv, rp)
+        if rank == world - 1 and recv.size:
+            recv[0] += 1.0
+    try:
+        startup_check(HostOps(sub, bad_exchange, allreduce), sub)
+        raise AssertionError("a corrupted ghost exchange passed the start-up check")
+    except _lib.ShaktiHipError as exc:
+        assert "start-up check failed" in str(exc) and f"rank {world - 1}" in str(exc)
     gid, no = sub.gid, sub.n_own
 
     def halo(vec):

@@ -178,3 +178,18 @@ def test_update_explicit_order_and_clamp():
     # (gh above differences nodal heads; the oracle differences each coefficient like FFCx: equal up to the
     #  rounding of ~1e3 m heads over these cells)
     assert np.allclose(f.q, -K[:, None] * gh, rtol=1e-10, atol=0)
+
+
+def test_conical_rule_is_an_exact_degree_7_rule():
+    """The alternative quadrature table of tests/test_gpu_sensitivity.py: 16 points, weights sum to 1/2, every monomial of
+    total degree <= 7 integrated exactly on the reference triangle, degree 8 not."""
+    from math import factorial
+    from cases import conical_rule
+    q = conical_rule(4)
+    assert q.shape == (16, 3) and abs(q[:, 2].sum() - 0.5) < 1e-15 and (q[:, 2] > 0).all()
+    assert (q[:, 0] > 0).all() and (q[:, 1] > 0).all() and (q[:, 0] + q[:, 1] < 1).all()
+    for a in range(8):
+        for b in range(8 - a):
+            exact = factorial(a) * factorial(b) / factorial(a + b + 2)
+            assert abs(np.sum(q[:, 2] * q[:, 0] ** a * q[:, 1] ** b) - exact) < 1e-14 * exact + 1e-18, (a, b)
+    assert abs(np.sum(q[:, 2] * q[:, 0] ** 8) - factorial(8) / factorial(10)) > 1e-7
