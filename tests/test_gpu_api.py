@@ -146,3 +146,43 @@ def test_editing_params_py_changes_the_solve(tmp_path, monkeypatch):
     assert rel_l2(N[-1], fo.N) < 1e-7
     f2, _ = O.run(md.domain.xy, md.domain.cells, _oracle_fields(md), md.timesteps, O.Params(), dofs, val, nsteps=md.timesteps.size)
     assert rel_l2(N[-1], f2.N) > 1e-4            # the default constants give a visibly different answer
+
+
+def test_a_poisoned_context_fails_fast_and_tears_down_without_waiting():
+    """What the RCCL deadline does when it fires (shk_comm_mark_stalled does the same from outside): every later call
+    that would wait for the device raises at once, and shk_destroy returns without synchronising the stream, destroying
+    the communicator or freeing device memory -- all of which would block behind a stalled collective -- so that the rank
+    can exit non-zero and the launcher tears the job down."""
+    import time
+    from shakti_fenics_amd import _lib
+    from shakti_fenics_amd.mesh import rectangle_mesh
+    dom = rectangle_mesh(33, 25, 10e3, 8e3)
+    ctx = _lib.ShaktiHip(dom.xy, dom.cells)
+    ctx.set_field("N", np.full(dom.num_vertices, 3.7e5))
+    ctx.comm_mark_stalled()
+    with pytest.raises(_lib.ShaktiCommStall):
+        ctx.sync()
+    with pytest.raises(_lib.ShaktiCommStall):
+        ctx.get_field("N")
+    t0 = time.perf_counter()
+    ctx.close()
+    assert time.perf_counter() - t0 < 2.0
+    # the process goes on: a fresh context works
+    ctx = _lib.ShaktiHip(dom.xy, dom.cells)
+    ctx.sync()
+    ctx.close()
+
+
+def test_experiment_switches_are_validated_not_trusted():
+    """SHK_ASM_SLICES outside the kernel's 1..4 is refused at context creation (it used to corrupt the Jacobian silently);
+    the timing-only transport needs a communicator."""
+    from shakti_fenics_amd import _lib
+    from shakti_fenics_amd.mesh import rectangle_mesh
+    dom = rectangle_mesh(33, 25, 10e3, 8e3)
+    with _lib.tunables(SHK_ASM_SLICES=5):
+        with pytest.raises(_lib.ShaktiHipError, match="1..4"):
+            _lib.ShaktiHip(dom.xy, dom.cells)
+    ctx = _lib.ShaktiHip(dom.xy, dom.cells)
+    with pytest.raises(_lib.ShaktiHipError, match="communicator"):
+        ctx.comm_set_timing_only(True)
+    ctx.close()
