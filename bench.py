@@ -277,6 +277,9 @@ def main():
         },
     }
     out["env_overrides"] = switches or None
+    out["assembly_passes"] = dict(run.ctx.solver_stats(), note="since context creation (warm-up included): full = residual + Jacobian; "
+                                  "residual_only = the pass after the update predicted to be a Newton solve's last (its Jacobian "
+                                  "would be thrown away); redone = full passes repeated because that prediction was wrong")
     if world == 1:
         # the same transient read through fixed windows: the timed region above is whatever --steps / --warmup say (the
         # driver's command: 20 after 5; the default: 8 after 1), and the metric counts Newton iterations, which fall from

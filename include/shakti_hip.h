@@ -241,6 +241,13 @@ int shk_profile_read(shk_ctx* ctx, shk_profile* out, int32_t reset);
 /* Launch kernel `phase` (SHK_PH_ASSEMBLE or SHK_PH_SPMV) `reps` times between two events. */
 int shk_time_kernel(shk_ctx* ctx, int32_t phase, int32_t reps, double dt, double* avg_ms);
 
+/* The residual-only instance of the assembly kernel (what shk_newton_solve launches after the update it expects to be
+ * the last of a solve: no element Jacobians, no slot phase), `reps` times between two events. */
+int shk_time_assemble_residual(shk_ctx* ctx, int32_t reps, double dt, double* avg_ms);
+/* Assembly passes since creation: n[0] full (residual + Jacobian), n[1] residual-only (predicted last iteration of a
+ * Newton solve), n[2] full passes repeated because the prediction was wrong, n[3] Newton iterations of the last solve. */
+int shk_solver_stats(shk_ctx* ctx, int64_t n[4]);
+
 /* Plan statistics for DESIGN.md / bench: n[0]=owned rows n[1]=ne n[2]=nnz n[3]=assembly blocks
  * n[4]=cells computed per assembly incl. cells shared between blocks n[5]=SELL slots (padded nnz)
  * n[6]=device bytes n[7]=max row length n[8]=entries of the finest A*P operator (0 if none)

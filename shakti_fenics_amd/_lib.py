@@ -66,7 +66,7 @@ EXPORTS = (
     "shk_get_params", "shk_set_quadrature", "shk_set_field", "shk_get_field", "shk_set_dirichlet",
     "shk_assemble", "shk_get_residual", "shk_csr_nnz", "shk_get_csr", "shk_linear_solve", "shk_spmv",
     "shk_newton_solve", "shk_update_explicit", "shk_step", "shk_sync", "shk_profile_enable",
-    "shk_profile_read", "shk_time_kernel", "shk_plan_stats", "shk_set_halo", "shk_comm_unique_id",
+    "shk_profile_read", "shk_time_kernel", "shk_time_assemble_residual", "shk_solver_stats", "shk_plan_stats", "shk_set_halo", "shk_comm_unique_id",
     "shk_comm_init_rccl", "shk_comm_init_callbacks", "shk_comm_selftest", "shk_comm_set_timing_only", "shk_comm_mark_stalled", "shk_comm_allreduce_check", "shk_env_overrides", "shk_tunable_set", "shk_comm_stats", "shk_comm_overlap", "shk_halo_update", "shk_interp_regular_grid",
     "shk_points_in_polygon",
 )
@@ -117,6 +117,8 @@ def load():
         "shk_profile_read": ([vp, P(shk_profile), i32], C.c_int),
         "shk_time_kernel": ([vp, i32, i32, dbl, P(dbl)], C.c_int),
         "shk_plan_stats": ([vp, P(i64)], C.c_int),
+        "shk_time_assemble_residual": ([vp, i32, dbl, P(dbl)], C.c_int),
+        "shk_solver_stats": ([vp, P(i64)], C.c_int),
         "shk_set_halo": ([vp, i32, vp, vp, vp, vp], C.c_int),
         "shk_comm_unique_id": ([vp], C.c_int),
         "shk_comm_init_rccl": ([vp, i32, i32, vp], C.c_int),
@@ -448,6 +450,17 @@ class ShaktiHip:
         ms = C.c_double()
         self._check(self.lib.shk_time_kernel(self._h, PHASES.index(phase), reps, float(dt), C.byref(ms)))
         return ms.value
+
+    def time_assemble_residual(self, reps: int, dt: float = 3600.0) -> float:
+        ms = C.c_double()
+        self._check(self.lib.shk_time_assemble_residual(self._h, reps, float(dt), C.byref(ms)))
+        return ms.value
+
+    def solver_stats(self) -> dict:
+        n = (C.c_int64 * 4)()
+        self._check(self.lib.shk_solver_stats(self._h, n))
+        return dict(assemblies_full=int(n[0]), assemblies_residual_only=int(n[1]), assemblies_redone=int(n[2]),
+                    newton_its_last_solve=int(n[3]))
 
     def plan_stats(self) -> dict:
         n = (C.c_int64 * 12)()

@@ -87,7 +87,10 @@ __device__ __forceinline__ int xcd_block(int b, int nb) {
 
 struct CellOut { double K[9], F[3]; };
 
-template <int NQ, int NP>
+// JAC = false: the residual-only instance (the pass after a Newton update that is expected to be the last: shk_api.hip,
+// shk_newton_solve): the element Jacobian is computed only for the few cells with a Dirichlet vertex, whose lifting
+// needs it; o.K is otherwise left untouched.
+template <int NQ, int NP, bool JAC>
 __device__ __forceinline__ void cell_tensor(const AsmArgs& a, const double* __restrict__ fld, const uint8_t* __restrict__ bcf,
                                             const QPoint* __restrict__ qk, const QPoint* __restrict__ qp, int V,
                                             int l0, int l1, int l2, CellOut& o) {
@@ -171,9 +174,11 @@ __device__ __forceinline__ void cell_tensor(const AsmArgs& a, const double* __re
         const double stor = sk * (Nk - Nnk) * a.inv_rwg_dt;        // solvers.py:42
         const double ws = w * (p.c_m * melt - closure - stor - ik);
         F0 += ws * f0; F1 += ws * f1; F2 += ws * f2;
-        const double wd = w * (p.A * p.n * bk * pw + sk * a.inv_rwg_dt);
-        T00 += wd * f0 * f0; T01 += wd * f0 * f1; T02 += wd * f0 * f2;
-        T11 += wd * f1 * f1; T12 += wd * f1 * f2; T22 += wd * f2 * f2;
+        if constexpr (JAC) {
+            const double wd = w * (p.A * p.n * bk * pw + sk * a.inv_rwg_dt);
+            T00 += wd * f0 * f0; T01 += wd * f0 * f1; T02 += wd * f0 * f2;
+            T11 += wd * f1 * f1; T12 += wd * f1 * f2; T22 += wd * f2 * f2;
+        }
     };
     if constexpr (NP > 0) {
 #pragma unroll SHK_UNROLL_P
@@ -185,6 +190,23 @@ __device__ __forceinline__ void cell_tensor(const AsmArgs& a, const double* __re
     double Fe0 = sK * (ghx * g0x + ghy * g0y) + F0;
     double Fe1 = sK * (ghx * g1x + ghy * g1y) + F1;
     double Fe2 = sK * (ghx * g2x + ghy * g2y) + F2;
+    const int bc0 = bcf[l0], bc1 = bcf[l1], bc2 = bcf[l2];
+    if constexpr (!JAC) {
+        if (!(bc0 | bc1 | bc2)) { o.F[0] = Fe0; o.F[1] = Fe1; o.F[2] = Fe2; return; }
+        // a cell with a Dirichlet vertex: its lifting needs the element Jacobian after all (a handful of cells per block)
+        const int np_ = NP > 0 ? NP : a.qpoly.nq;
+        for (int k = 0; k < np_; ++k) {
+            const QPoint q = NP > 0 ? QPoint{a.qpoly.phi0[k], a.qpoly.phi1[k], a.qpoly.phi2[k], a.qpoly.w2[k]} : qp[k];
+            const double f0 = q.f0, f1 = q.f1, f2 = q.f2, w = q.w * area;
+            const double Nk = __builtin_fma(dN2, f2, __builtin_fma(dN1, f1, N0));
+            const double bk = __builtin_fma(db2, f2, __builtin_fma(db1, f1, b0));
+            const double sk = __builtin_fma(ds2, f2, __builtin_fma(ds1, f1, s0));
+            const double pw = p.n_is_3 ? Nk * Nk : pow(fabs(Nk), p.n - 1.0);
+            const double wd = w * (p.A * p.n * bk * pw + sk * a.inv_rwg_dt);
+            T00 += wd * f0 * f0; T01 += wd * f0 * f1; T02 += wd * f0 * f2;
+            T11 += wd * f1 * f1; T12 += wd * f1 * f2; T22 += wd * f2 * f2;
+        }
+    }
     const double kk = -sK * p.inv_rwg;
     const double d00 = g0x * g0x + g0y * g0y, d01 = g0x * g1x + g0y * g1y, d02 = g0x * g2x + g0y * g2y;
     const double d11 = g1x * g1x + g1y * g1y, d12 = g1x * g2x + g1y * g2y, d22 = g2x * g2x + g2y * g2y;
@@ -202,7 +224,6 @@ __device__ __forceinline__ void cell_tensor(const AsmArgs& a, const double* __re
     o.K[6] = kk * d02 + (Px2 * g0x + Py2 * g0y) - T02;
     o.K[7] = kk * d12 + (Px2 * g1x + Py2 * g1y) - T12;
     o.K[8] = kk * d22 + (Px2 * g2x + Py2 * g2y) - T22;
-    const int bc0 = bcf[l0], bc1 = bcf[l1], bc2 = bcf[l2];
     if (bc0 | bc1 | bc2) {
         // apply_lifting(alpha=-1): F_i += K_ij (g - N_j) over Dirichlet columns j
         const double e0 = bc0 ? a.bc_value - N0 : 0.0;
@@ -217,7 +238,7 @@ __device__ __forceinline__ void cell_tensor(const AsmArgs& a, const double* __re
 
 // T threads per workgroup; NQ / NP: points of the two rules when they are the built-in ones (15 / 7: loops fully
 // unrolled), 0 = run-time counts (a user table from shk_set_quadrature, or Glen's n != 3).
-template <int T, int NQ, int NP>
+template <int T, int NQ, int NP, bool JAC = true>
 __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) {
     constexpr int R = (kAsmCellsMax + T - 1) / T;   // cells per thread
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -302,7 +323,7 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
 #pragma unroll
                 for (int k = 0; k < 3; ++k) out[r].F[k] = fld[cv.y] + fld[cv.z];
             } else {
-                cell_tensor<NQ, NP>(a, fld, bcf, qk, qp, V, cv.x, cv.y, cv.z, out[r]);
+                cell_tensor<NQ, NP, JAC>(a, fld, bcf, qk, qp, V, cv.x, cv.y, cv.z, out[r]);
             }
         }
     }
@@ -310,20 +331,24 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
     // registers they would otherwise crowd (they cost 80 B per lane of scratch spills = 0.8 GB of traffic per pass when
     // requested at kernel start; with the 48 registers the scalar quadrature tables freed, still 1.74 against 1.70 ms)
     // -- and arrive while the tensors go to LDS
-    constexpr int kSlotIt = (kAsmSlotsMax + T - 1) / T;
+    constexpr int kSlotIt = JAC ? (kAsmSlotsMax + T - 1) / T : 1;
     uint32_t srcw[kSlotIt];
+    if constexpr (JAC) {
 #pragma unroll
-    for (int r = 0; r < kSlotIt; ++r) {
-        const int s = n0 + tid + r * T;
-        srcw[r] = s < n1 ? a.slotsrc[s] : kSrcEmpty;
+        for (int r = 0; r < kSlotIt; ++r) {
+            const int s = n0 + tid + r * T;
+            srcw[r] = s < n1 ? a.slotsrc[s] : kSrcEmpty;
+        }
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int t = tid + r * T;
         if (t < ncell) {
+            if constexpr (JAC) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) et[k * E + t] = out[r].K[k];
+                for (int k = 0; k < 9; ++k) et[k * E + t] = out[r].K[k];
+            }
 #pragma unroll
             for (int k = 0; k < 3; ++k) et[(9 + k) * E + t] = out[r].F[k];
         }
@@ -344,7 +369,8 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
         if (bcf[i]) sum = a.fld[0][v] - a.bc_value;  // set_bc(b, bcs, x, -1): F = N - g
         a.F[v] = sum;
     }
-    // ---- phase 2a: one thread per SELL slot of the owned slices ----
+    // ---- phase 2a: one thread per SELL slot of the owned slices (not in the residual-only instance) ----
+    if constexpr (!JAC) return;
     if (!SHK_ABLATE(2)) {
         // first slot of the block's 2nd .. 4th slice (INT_MAX when absent): a slot's slice by three compares
         const int sp1 = ns > 1 ? sp[1] : 0x7FFFFFFF, sp2 = ns > 2 ? sp[2] : 0x7FFFFFFF, sp3 = ns > 3 ? sp[3] : 0x7FFFFFFF;
@@ -437,12 +463,18 @@ size_t assemble_lds_bytes(const HostPlan& P, size_t* region_a) {
     return (lds + 15) & ~size_t(15);
 }
 
-void launch_assemble(Ctx* c, double dt) {
+void launch_assemble(Ctx* c, double dt, bool residual_only) {
     AsmArgs a;
     fill_asm_args(c, dt, a);
     // host-side check of what the kernel's fixed loop counts assume (a violation would write outside its LDS)
     if (a.cells_max > kAsmCellsMax || a.verts_max > kAsmVertsMax) { set_error("assembly plan exceeds the kernel's staging limits"); return; }
     const bool builtin = a.quad.nq == 15 && a.qpoly.nq == 7;
+    if (residual_only) {   // no plan words, no values, no 1/diag
+        note_bytes(c, c->asm_bytes - 12.0 * (double)c->slots - 8.0 * (double)c->n_own);
+        if (builtin) launch_phase(c, SHK_PH_ASSEMBLE, k_assemble<kBlock, 15, 7, false>, dim3(c->nblk), dim3(kBlock), c->asm_lds, a);
+        else launch_phase(c, SHK_PH_ASSEMBLE, k_assemble<kBlock, 0, 0, false>, dim3(c->nblk), dim3(kBlock), c->asm_lds, a);
+        return;
+    }
     note_bytes(c, c->asm_bytes);
     if (builtin) launch_phase(c, SHK_PH_ASSEMBLE, k_assemble<kBlock, 15, 7>, dim3(c->nblk), dim3(kBlock), c->asm_lds, a);
     else launch_phase(c, SHK_PH_ASSEMBLE, k_assemble<kBlock, 0, 0>, dim3(c->nblk), dim3(kBlock), c->asm_lds, a);
@@ -450,7 +482,9 @@ void launch_assemble(Ctx* c, double dt) {
 
 // Dynamic LDS above 64 KiB has to be requested per kernel.
 hipError_t prepare_kernels(Ctx* c) {
-    const void* fns[] = {reinterpret_cast<const void*>(&k_assemble<kBlock, 15, 7>), reinterpret_cast<const void*>(&k_assemble<kBlock, 0, 0>)};
+    const void* fns[] = {reinterpret_cast<const void*>(&k_assemble<kBlock, 15, 7>), reinterpret_cast<const void*>(&k_assemble<kBlock, 0, 0>),
+                         reinterpret_cast<const void*>(&k_assemble<kBlock, 15, 7, false>),
+                         reinterpret_cast<const void*>(&k_assemble<kBlock, 0, 0, false>)};
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->asm_lds);
         if (e != hipSuccess) return e;

@@ -530,7 +530,10 @@ struct Ctx {
     int32_t* d_bslices = nullptr;       // those slices, ascending
     int n_bslices = 0;
     double* d_part_b = nullptr;         // P_COUNT arrays of kMaxParts: partial sums of the boundary passes
-    bool assembled = false;
+    bool assembled = false;   // d_F holds the residual of the current state
+    bool jac_valid = false;   // ... and d_vals / d_dinv its Jacobian (false after a residual-only pass)
+    int newton_prev = 0;      // Newton iterations of the previous shk_newton_solve (predicts the last iteration of this one)
+    int64_t n_asm_full = 0, n_asm_res = 0, n_asm_redo = 0;   // assembly passes: full, residual-only, full after a misprediction
     double assembled_dt = 0.0;
     bool poisoned = false;   // a host wait hit the RCCL deadline (or shk_comm_mark_stalled): the stream will never drain, so
                              // shk_destroy must neither synchronise nor free (both would block for ever)
@@ -581,7 +584,7 @@ int set_error(const std::string& msg);
 // launchers (shk_kernels.hip)
 hipError_t prepare_kernels(Ctx* c);
 size_t assemble_lds_bytes(const HostPlan& P, size_t* region_a);
-void launch_assemble(Ctx* c, double dt);
+void launch_assemble(Ctx* c, double dt, bool residual_only = false);
 void launch_slot_bc(Ctx* c);
 void launch_scale(Ctx* c);
 void launch_spmv_plain(Ctx* c, const double* vals, const double* x, double* y);
