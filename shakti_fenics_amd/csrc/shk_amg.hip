@@ -409,14 +409,19 @@ struct AmgFirstArgs {
     int32_t n_ghost;
     float* xo2;
 };
-template <bool FINE, class TR>
+// GHOSTS: the instance that also fills the ghost columns (decomposed levels with frozen ghosts).  A separate instance
+// because the mere presence of that (zero-trip) loop cost the one-subdomain kernel 25 % (97 -> 121 us at 10M rows: 16 more
+// registers and a differently scheduled slice loop); without it the kernel is the one rounds 1-2 measured.
+template <bool FINE, class TR, bool GHOSTS = false>
 __global__ __launch_bounds__(kBlock) void k_amg_first(const AmgFirstArgs<TR> a) {
     if (*a.done) return;
     const int lane = threadIdx.x & 63;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n_ghost; i += gridDim.x * kBlock) {
-        const float v = a.alpha * a.e[a.ghost_col[i]];
-        a.xo[a.AP.n_rows + i] = v;
-        if (a.xo2) a.xo2[a.AP.n_rows + i] = v;
+    if constexpr (GHOSTS) {
+        for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n_ghost; i += gridDim.x * kBlock) {
+            const float v = a.alpha * a.e[a.ghost_col[i]];
+            a.xo[a.AP.n_rows + i] = v;
+            if (a.xo2) a.xo2[a.AP.n_rows + i] = v;
+        }
     }
     for (SliceLoop it(a.AP, wave_index()); it.valid(); it.next()) {
         const int row = min(it.s * kSlice + lane, a.AP.n_rows - 1);
@@ -1358,7 +1363,8 @@ static hipError_t amg_vcycle_t(Ctx* c, AmgHierarchy& H, const TR* rin, float* zo
                                    X.ap_vals, H.top_dinv, rin, e_cols, X.agg, agg_off, H.x0, omega, alpha, done,
                                    frozen ? X.ghost_col : nullptr, frozen ? X.n_ghost : 0, nullptr};
                 note_bytes(c, first_bytes);
-                launch_phase(c, ph(SHK_PH_AMG_FIRST), k_amg_first<true, TR>, g, dim3(kBlock), 0, f);
+                if (frozen) launch_phase(c, ph(SHK_PH_AMG_FIRST), k_amg_first<true, TR, true>, g, dim3(kBlock), 0, f);
+                else launch_phase(c, ph(SHK_PH_AMG_FIRST), k_amg_first<true, TR>, g, dim3(kBlock), 0, f);
             } else {
                 {
                     PhaseTimer t(c, ph(SHK_PH_AMG_COARSE));
@@ -1406,7 +1412,8 @@ static hipError_t amg_vcycle_t(Ctx* c, AmgHierarchy& H, const TR* rin, float* zo
                                       frozen ? X.ghost_col : nullptr, frozen ? X.n_ghost : 0, L.x2};
                 PhaseTimer t(c, ph_level(l));
                 note_bytes(c, first_bytes);
-                hipLaunchKernelGGL((k_amg_first<false, float>), g, dim3(kBlock), 0, c->stream, f);
+                if (frozen) hipLaunchKernelGGL((k_amg_first<false, float, true>), g, dim3(kBlock), 0, c->stream, f);
+                else hipLaunchKernelGGL((k_amg_first<false, float>), g, dim3(kBlock), 0, c->stream, f);
             } else {
                 {
                     PhaseTimer t(c, ph_level(l));

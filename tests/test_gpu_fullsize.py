@@ -20,7 +20,10 @@ pytestmark = pytest.mark.gpu
 DT = 3600.0
 
 
-@pytest.fixture(scope="module", params=["c2_1m", "c4_10m"])
+# c2_1m / c4_10m: BASELINE.json's jittered rectangles; basin_10m: the genuinely unstructured 10.5M-DOF Delaunay basin mesh
+# (graded spacing, a hole, a curved outlet, valence-13 vertices -> rows of 14 entries, random vertex order) on the same
+# 100 km x 20 km footprint -- BASELINE config 4 says "unstructured" (its mesh generation takes ~2 minutes of Qhull)
+@pytest.fixture(scope="module", params=["c2_1m", "c4_10m", "basin_10m"])
 def big(request):
     from shakti_fenics_amd import _lib
     from shakti_fenics_amd.runner import SingleRunner

@@ -12,15 +12,22 @@ if [ "$1" = "pmc" ]; then
     rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_$ctr -- python3 tools/pmc_probe.py c4_10m > $out/pmc_$ctr.log 2>&1
     echo "pass $ctr done"
   done
+  # third pass: what binds the assembly kernel (fp64 VALU issue): wave-instructions and the share of cycles its waves wait
+  rm -rf $out/pmc_VALU
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $out/pmc_VALU -- python3 tools/pmc_probe.py c4_10m > $out/pmc_VALU.log 2>&1
+  echo "pass VALU done"
   slots=$(grep -o "slots [0-9]*" $out/pmc_FETCH_SIZE.log | head -1 | cut -d" " -f2)
   f=$(ls $out/pmc_FETCH_SIZE/*/*counter_collection.csv | head -1)
   w=$(ls $out/pmc_WRITE_SIZE/*/*counter_collection.csv | head -1)
-  python tools/pmc_to_json.py $f $w $((8 * slots)) $out/pmc_traffic_c4_10m.json > $out/pmc_to_json.log
-  rm -rf $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE
+  v=$(ls $out/pmc_VALU/*/*counter_collection.csv | head -1)
+  python tools/pmc_to_json.py $f $w $((8 * slots)) $out/pmc_traffic_c4_10m.json $v > $out/pmc_to_json.log
+  rm -rf $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmc_VALU
   tail -5 $out/pmc_to_json.log
 else
   python bench.py > $out/bench_default.json 2> $out/bench_default.err
   echo "bench done"
+  python bench.py --steps 20 --warmup 5 > $out/bench_steps20_warmup5.json 2> $out/bench_steps20_warmup5.err
+  echo "bench 20/5 done"
   rm -rf $out/prof
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 bench.py --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/bench_under_rocprof.err
   cp $(ls $out/prof/*/*kernel_stats.csv | head -1) $out/kernel_stats.csv

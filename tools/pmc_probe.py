@@ -15,5 +15,6 @@ print("nv", st["nv"], "nnz", st["nnz"], "slots", st["sell_slots"], "ne", st["ne"
 print("stream-read ms", c.time_kernel("other", 5), "bytes", 8 * st["sell_slots"], flush=True)
 print("spmv ms", c.time_kernel("spmv", 5), flush=True)
 print("assemble ms", c.time_kernel("assemble", 3, 360.0), flush=True)
+print("assemble (residual only) ms", c.time_assemble_residual(3, 360.0), flush=True)
 c.assemble(360.0)
 print("linear solve", c.linear_solve(), flush=True)
