@@ -328,7 +328,7 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
 extern "C" {
 
 const char* shk_last_error(void) { return g_err.c_str(); }
-int shk_version(void) { return 100; }
+int shk_version(void) { return 300; }   // round * 100: the ABI of include/shakti_hip.h as of round 3
 
 int shk_default_params(shk_params* p) {
     if (!p) return fail("null params");
