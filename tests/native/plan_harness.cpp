@@ -211,6 +211,116 @@ int main(int argc, char** argv) {
         CHECK("galerkin_plans_cover_every_entry_once", cover);
         CHECK("aggregates_have_members", members);
     }
+    // fused multi-sweep smoother plans (build_sweep_plan): for every sparse level with a plan, (1) the local index maps
+    // are consistent with the level's columns, (2) rings are closed (every column of a row that is recomputed is
+    // addressable), and (3) the temporally blocked evaluation -- four damped-Jacobi sweeps computed block by block on
+    // shrinking sets S3 > S2 > S1 > S0 from the plan's arrays alone -- equals four global sweeps (the first on A*P)
+    {
+        bool maps_ok = true, exact = true;
+        int planned = 0;
+        std::mt19937_64 rng(17);
+        std::uniform_real_distribution<double> U(0.1, 1.0);
+        for (size_t l = 0; l + 1 < P.amg.size(); ++l) {
+            if (P.amg[l].dense || !P.amg[l + 1].with_ap) break;
+            const SellPattern& A = P.amg[l].Ac;          // level l+1's operator
+            const AmgLevelPlan& T = P.amg[l + 1];        // its transfer: A*P pattern + aggregates
+            const SellPattern& Q = T.AP;
+            SweepPlan S;
+            CHECK("sweep_plan_builds", build_sweep_plan(A, Q, S).empty());
+            if (S.nblk == 0) continue;
+            ++planned;
+            const int n = A.n_rows, nc = T.n_coarse_cols, W = S.width;
+            // random level data; A made diagonally dominant so that the sweeps stay bounded
+            std::vector<double> av(A.slots, 0.0), qv(Q.slots, 0.0), r(n), e(nc), dinv(n);
+            for (int i = 0; i < n; ++i) {
+                const int s = i / kSlice, li = i % kSlice, base = A.ptr[s];
+                double off = 0.0;
+                for (int k = 1; k < A.rowlen[i]; ++k) { av[base + k * kSlice + li] = -U(rng); off += std::fabs(av[base + k * kSlice + li]); }
+                av[base + li] = off + 1.0;
+                dinv[i] = 1.0 / av[base + li];
+                const int qb = Q.ptr[s];
+                for (int k = 0; k < Q.rowlen[i]; ++k) qv[qb + k * kSlice + li] = U(rng) - 0.5;
+                r[i] = U(rng);
+            }
+            for (double& v : e) v = U(rng) - 0.5;
+            const double w[4] = {0.4, 1.1, 0.5, 0.8}, alpha = 1.5;
+            // reference: four global sweeps
+            std::vector<double> x(n), y(n);
+            auto arow = [&](int i, const std::vector<double>& xin) {
+                const int s = i / kSlice, li = i % kSlice, base = A.ptr[s];
+                double sum = 0.0;
+                for (int k = 0; k < A.rowlen[i]; ++k) sum += av[base + k * kSlice + li] * xin[A.col[base + k * kSlice + li]];
+                return sum;
+            };
+            for (int i = 0; i < n; ++i) {
+                const int s = i / kSlice, li = i % kSlice, qb = Q.ptr[s];
+                double sum = 0.0;
+                for (int k = 0; k < Q.rowlen[i]; ++k) sum += qv[qb + k * kSlice + li] * e[Q.col[qb + k * kSlice + li]];
+                x[i] = alpha * e[T.agg[i]] + w[0] * dinv[i] * (r[i] - alpha * sum);
+            }
+            for (int sw = 1; sw < 4; ++sw) {
+                for (int i = 0; i < n; ++i) y[i] = x[i] + w[sw] * dinv[i] * (r[i] - arow(i, x));
+                x.swap(y);
+            }
+            // blocked evaluation from the plan
+            std::vector<double> out(n, 0.0);
+            for (int b = 0; b < S.nblk && maps_ok; ++b) {
+                const int r0 = b * kSweepRows, n0 = std::min(n - r0, kSweepRows);
+                const int32_t* hd = &S.hdr[8 * (size_t)b];
+                const int nS1 = kSweepRows + hd[2], nS2 = nS1 + hd[3], nS3 = nS2 + hd[4], nfix = hd[5];
+                maps_ok = maps_ok && nS2 <= kSweepMaxS2 && nS3 <= kSweepMaxS3 && nS3 + nfix <= kSweepMaxLocal && nfix == 0;
+                const int32_t* info = &S.ext_info[4 * (size_t)hd[0]];
+                std::vector<int> grow(nS3, -1);                    // local id -> level row
+                for (int t = 0; t < n0; ++t) grow[t] = r0 + t;
+                for (int t = kSweepRows; t < nS3; ++t) grow[t] = info[4 * (t - kSweepRows)];
+                std::vector<double> xa(nS3, 0.0), xb(nS3, 0.0);
+                for (int t = 0; t < nS3; ++t) {
+                    const int g = grow[t];
+                    if (g < 0) continue;
+                    const int pbase = t < n0 ? Q.ptr[g / kSlice] + g % kSlice : info[4 * (t - kSweepRows) + 2];
+                    const int plen = t < n0 ? Q.rowlen[g] : info[4 * (t - kSweepRows) + 3] >> 8;
+                    maps_ok = maps_ok && pbase == Q.ptr[g / kSlice] + g % kSlice && plen == Q.rowlen[g];
+                    double sum = 0.0;
+                    for (int k = 0; k < plen; ++k) sum += qv[pbase + k * kSlice] * e[Q.col[pbase + k * kSlice]];
+                    xa[t] = alpha * e[T.agg[g]] + w[0] * dinv[g] * (r[g] - alpha * sum);
+                }
+                auto sweep = [&](const std::vector<double>& xin, std::vector<double>& xout, int upto, double ww) {
+                    for (int t = 0; t < upto; ++t) {
+                        const int g = grow[t];
+                        if (g < 0) continue;
+                        double sum = 0.0;
+                        if (t < n0) {
+                            const int base = A.ptr[g / kSlice] + g % kSlice, wid = (A.ptr[g / kSlice + 1] - A.ptr[g / kSlice]) / kSlice;
+                            for (int k = 0; k < wid; ++k) {
+                                const int lc = S.lcol_own[base + k * kSlice];
+                                if (k < A.rowlen[g]) maps_ok = maps_ok && lc < nS3 && grow[lc] == A.col[base + k * kSlice];
+                                sum += av[base + k * kSlice] * xin[lc];
+                            }
+                        } else {
+                            const int base = info[4 * (t - kSweepRows) + 1], len = info[4 * (t - kSweepRows) + 3] & 255;
+                            const uint16_t* lc = &S.ring_lcol[((size_t)hd[1] + (t - kSweepRows)) * W];
+                            maps_ok = maps_ok && base == A.ptr[g / kSlice] + g % kSlice && len == A.rowlen[g];
+                            for (int k = 0; k < len; ++k) {
+                                maps_ok = maps_ok && lc[k] < nS3 && grow[lc[k]] == A.col[base + k * kSlice];
+                                sum += av[base + k * kSlice] * xin[lc[k]];
+                            }
+                        }
+                        xout[t] = xin[t] + ww * dinv[g] * (r[g] - sum);
+                    }
+                };
+                sweep(xa, xb, nS2, w[1]);
+                sweep(xb, xa, nS1, w[2]);
+                sweep(xa, xb, n0, w[3]);
+                for (int t = 0; t < n0; ++t) out[r0 + t] = xb[t];
+            }
+            double worst = 0.0;
+            for (int i = 0; i < n; ++i) worst = std::max(worst, std::fabs(out[i] - x[i]));
+            exact = exact && worst <= 1e-12;
+        }
+        CHECK("sweep_plan_maps_consistent", maps_ok);
+        CHECK("blocked_sweeps_equal_global_sweeps", exact);
+        std::printf("sweep_plans %d\n", planned);
+    }
     // the replicated-level path on ONE "subdomain": coarse_rows + sell_from_csr + coarsen_onto_global must produce
     // the same coarse operator as the ordinary transfer, entry by entry
     if (!P.amg.empty() && !P.amg[0].dense) {

@@ -376,3 +376,89 @@ def test_user_quadrature_table_is_honoured(hip):
     with pytest.raises(hip.ShaktiHipError):
         ctx.set_quadrature(q0 * 2.0)   # weights no longer sum to 1/2
     ctx.close()
+
+
+def test_fused_four_sweep_smoother_is_the_same_preconditioner(hip):
+    """k_amg_sweeps (the four sweeps of every multigrid level of <= 200k rows in ONE launch, temporally blocked) against
+    the four separate launches it replaces, on a 250k-DOF mesh (levels of 62k, 16k and 4k rows take the fused path): the
+    same preconditioner up to float rounding, hence the same solution and Krylov iteration counts within a few.  The plan's exactness is checked on the host too (tests/native/plan_harness.cpp)."""
+    from shakti_fenics_amd.mesh import rectangle_mesh
+    from shakti_fenics_amd.synthetic import N_BDRY, outflow_predicate, synthetic_fields
+    dom = rectangle_mesh(1118, 224, 100e3, 20e3, order="morton")
+    sf = synthetic_fields(dom, storage_on=True, moulins=4)
+    nv = dom.num_vertices
+    f = O.Fields(N=sf["N_init"].copy(), N_n=sf["N_init"].copy(), b=np.abs(sf["b_init"]), q=sf["q_init"].copy(),
+                 melt_n=np.zeros(nv), z_b=sf["z_b"], z_s=sf["z_s"], G=sf["G"], storage=sf["lake_bdry"], inputs=sf["inputs"])
+    bc = O.boundary_dofs(dom.xy, dom.cells, outflow_predicate(dom))
+    out = {}
+    for mode in ("1", "0"):
+        with hip.tunables(SHK_AMG_FUSED_SWEEPS=mode):
+            ctx = hip.ShaktiHip(dom.xy, dom.cells)
+        ctx.set_params(precond=hip.PRECOND["amg"])
+        upload(ctx, f, bc, N_BDRY)
+        ctx.assemble(360.0)
+        its, conv, rr = ctx.linear_solve()
+        assert conv
+        ctx.profile_enable(True)
+        ctx.profile_read(reset=True)
+        ctx.assemble(360.0)
+        ctx.linear_solve()
+        prof = ctx.profile_read(reset=True)
+        ctx.profile_enable(False)
+        out[mode] = (its, ctx.get_field("dx"), sum(prof[f"amg_l{l}"]["launches"] for l in range(2, 6)))
+        ctx.close()
+    assert rel_l2(out["0"][1], out["1"][1]) < 1e-8
+    # (not bit-identical: the streaming sweeps add a row's products in chunks of 8 slots, the fused kernel in one running
+    #  sum -- float rounding at 1e-7, which BiCGStab turns into a few iterations either way: 38 / 41 here, 551 / 554-563
+    #  over the 20 bench steps at 10M DOF)
+    assert abs(out["0"][0] - out["1"][0]) <= max(3, 0.1 * out["0"][0]), (out["0"][0], out["1"][0])
+    assert out["1"][2] < 0.5 * out["0"][2], (out["1"][2], out["0"][2])     # far fewer launches on the small levels
+
+
+@pytest.mark.parametrize("with_bc", [False, True])
+def test_residual_only_assembly_equals_the_full_pass(hip, with_bc):
+    """The residual-only kernel instance (launched for the pass after the update expected to be a Newton solve's last)
+    writes the same residual as the full pass -- Dirichlet lifting included, which needs the element Jacobian of the cells
+    with a Dirichlet vertex -- and leaves the Jacobian alone."""
+    dom, f, bc, g = make_case(perturb=True, raw_b=True)
+    if with_bc:
+        f.N[bc[::2]] = g
+    ctx = hip.ShaktiHip(dom.xy, dom.cells)
+    upload(ctx, f, bc if with_bc else None, g)
+    ctx.assemble(DT)
+    F_full = ctx.residual()
+    rp, ci, va = ctx.csr()
+    ctx.time_assemble_residual(1, DT)
+    F_res = ctx.residual()
+    scale = np.abs(F_full).max()
+    assert np.abs(F_res - F_full).max() <= 1e-15 * scale
+    with pytest.raises(hip.ShaktiHipError):
+        ctx.csr()                       # the Jacobian is not that of a residual-only pass: reading it is refused
+    ctx.assemble(DT)
+    assert np.array_equal(ctx.csr()[2], va)
+    ctx.close()
+
+
+def test_newton_solve_predicts_its_last_iteration_without_changing_results(hip):
+    """With and without the residual-only pass for the predicted-last Newton iteration (SHK_PREDICT_LAST): identical Newton
+    counts, fields equal to the last bit of the linear solves' tolerance, and the passes are counted."""
+    dom, f, bc, g = make_case(nx=61, ny=61, Lx=100e3, Ly=100e3, moulins=3)
+    res = {}
+    for mode in ("1", "0"):
+        with hip.tunables(SHK_PREDICT_LAST=mode):
+            ctx = hip.ShaktiHip(dom.xy, dom.cells)
+            ctx.set_params(precond=hip.PRECOND["amg"])
+            upload(ctx, f, bc, g)
+            its = []
+            for i in range(8):
+                info = ctx.step(0.1 * DT if i == 0 else DT)
+                assert info.converged
+                its.append(info.newton_its)
+            res[mode] = (its, ctx.get_field("N"), ctx.get_field("b"), ctx.solver_stats())
+            ctx.close()
+    assert res["1"][0] == res["0"][0]
+    assert rel_l2(res["1"][1], res["0"][1]) < 1e-9 and rel_l2(res["1"][2], res["0"][2]) < 1e-9
+    assert res["0"][3]["assemblies_residual_only"] == 0
+    assert res["1"][3]["assemblies_residual_only"] >= 4          # the steady 2-iteration steps end on a residual-only pass
+    assert res["1"][3]["assemblies_full"] + res["1"][3]["assemblies_residual_only"] - res["1"][3]["assemblies_redone"] \
+        == res["0"][3]["assemblies_full"]

@@ -55,15 +55,19 @@ def test_plan_invariants(harness, tmp_path, nx, ny, order):
     nv, ne = dom.num_vertices, dom.num_cells
     assert int(lines["nnz"]) == nv + 2 * (nv + ne - 1)
     assert int(lines["levels"]) >= 2 and int(lines["rep_levels"]) >= 1
+    # the fused four-sweep smoother's plans: built for at least one level of the two larger meshes and -- checked inside
+    # the harness -- exactly equivalent to four global sweeps
+    # (a level gets one when it is run by launches, i.e. has more than 4096 rows: level 1 of the 17.5k-vertex mesh)
+    assert int(lines["sweep_plans"]) >= (1 if nx * ny > 4 * 4096 else 0)
 
 
 def test_plan_invariants_on_the_unstructured_basin_mesh(harness, tmp_path):
     """Delaunay mesh with a hole, graded spacing, vertices of valence up to 13, random vertex order."""
     from shakti_fenics_amd.mesh import basin_mesh
-    dom = basin_mesh(9000, order="random")
+    dom = basin_mesh(21000, order="random")
     _write_mesh(tmp_path / "mesh.bin", dom)
     lines = _run([harness, str(tmp_path / "mesh.bin")])
-    assert int(lines["max_row_len"]) >= 10 and int(lines["levels"]) >= 2
+    assert int(lines["max_row_len"]) >= 10 and int(lines["levels"]) >= 2 and int(lines["sweep_plans"]) >= 1
 
 
 @pytest.mark.parametrize("mesh,nparts", [("rectangle", 8), ("basin", 3)])
