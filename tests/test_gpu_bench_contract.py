@@ -40,3 +40,32 @@ def test_bench_line_has_every_contract_field():
     assert cpu["kind"] == "port" and cpu["cores"] == 1 and set(cpu["legs"]) >= {"sample_lu", "c1_5k_lu", "c1_5k_bicgstab"}
     assert d["strict_linear_solves"]["krylov_its_per_newton"] >= d["config"]["krylov_its_per_newton"]
     assert d["steady_state"]["ended_by"] in ("tolerance", "step limit")
+    # round 3: needed-bytes pricing with the 8d figure beside it, whole-step utilisation, per-level times, fixed windows
+    assert roof["algorithmic"]["bytes_per_launch"] >= roof["bytes_per_launch"] > 0
+    assert 0 < roof["step"]["frac"] < 1 and roof["step"]["bytes"] > 0 and "coarse_levels" in roof
+    assert roof["kernels"]["assemble"]["bound"] == "fp64 valu"
+    assert set(d["windows"]) >= {"steps_1_8", "steps_5_24", "per_step"} and d["windows"]["steps_1_8"]["newton_its"] > 0
+    assert d["env_overrides"] is None and d["assembly_passes"]["assemblies_full"] > 0
+
+
+def test_bench_line_of_a_two_rank_launch_reports_every_rank():
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` on one GPU (host-staged transport): the N > 1
+    path of the contract -- mesh built on rank 0 only, start-up check, one JSON line from rank 0 with the wiring and the
+    message rounds of EVERY rank (what the first real multi-GPU run prints)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29641", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "c2_1m", "--transport", "gloo",
+           "--steps", "3", "--warmup", "1", "--strict-steps", "0", "--no-roofline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["transport"] == "gloo" and d["config"]["parallelism"] == "dd2" and d["value"] > 0
+    assert [w["rank"] for w in d["ranks"]] == [0, 1] and all(w["n_ghost"] > 0 and w["neighbours"] for w in d["ranks"])
+    assert sum(w["n_own"] for w in d["ranks"]) == d["config"]["dofs"]
+    rounds = d["message_rounds_by_rank"]
+    assert len(rounds) == 2 and rounds[0]["exchanges"] == rounds[1]["exchanges"] > 0
+    # the padded all-reduces of rounds 1-2 are gone: scalars only; the replicated level travels by all-gathers
+    assert rounds[0]["bytes_allreduced"] < 1e3 and rounds[0]["allgathers"] > 0
+    assert "rank 1: device" in r.stderr and "rank 1: per Krylov iteration" in r.stderr
