@@ -117,6 +117,18 @@ const char* rccl_selftest(Ctx* c) {
         if (r1 != ncclSuccess || r2 != ncclSuccess || r3 != ncclSuccess) { err = "grouped ncclSend / ncclRecv on the second stream failed"; break; }
         if (hipEventRecord(arrived, side) != hipSuccess || hipStreamWaitEvent(c->stream, arrived, 0) != hipSuccess) { err = "event ordering failed"; break; }
         if (g_rccl.AllReduce(d + 2 * n, d + 3 * n, 4, ncclDouble, ncclSum, comm, c->stream) != ncclSuccess) { err = "ncclAllReduce failed"; break; }
+        // round 3's calls: a float exchange that lands in place (the multigrid vectors' ghosts) and the in-place
+        // ncclAllGather of bytes (the replicated level's right-hand side); the float view of d[0 .. n) is the payload
+        {
+            float* fl = reinterpret_cast<float*>(d);
+            g_rccl.GroupStart();
+            r1 = g_rccl.Send(fl, 64, ncclFloat, me, comm, c->stream);
+            r2 = g_rccl.Recv(fl + 2 * n - 64, 64, ncclFloat, me, comm, c->stream);   // the last 64 floats of d[0 .. n): overwritten
+            r3 = g_rccl.GroupEnd();
+            if (r1 != ncclSuccess || r2 != ncclSuccess || r3 != ncclSuccess) { err = "float ncclSend / ncclRecv failed"; break; }
+            char* blk = reinterpret_cast<char*>(d + n);   // in-place all-gather of this rank's block of 256 bytes
+            if (g_rccl.AllGather(blk + 256 * (size_t)me, blk, 256, ncclChar, comm, c->stream) != ncclSuccess) { err = "ncclAllGather failed"; break; }
+        }
         if (g_rccl.CommGetAsyncError) {
             ncclResult_t ae = ncclSuccess;
             if (g_rccl.CommGetAsyncError(comm, &ae) != ncclSuccess || (ae != ncclSuccess && ae != ncclInProgress)) { err = "asynchronous RCCL error"; break; }
@@ -129,6 +141,10 @@ const char* rccl_selftest(Ctx* c) {
             if (back[2 * n + i] != h[i]) err = "the exchange on the second stream delivered other values than the first round left";
         for (int i = 0; i < 4 && !err; ++i)
             if (back[3 * n + i] != c->comm.nranks * h[i] && c->comm.nranks == 1) err = "ncclAllReduce returned a wrong sum";
+        if (!err && std::memcmp(&back[n - 32], &back[0], 64 * sizeof(float)) != 0) err = "the float exchange delivered other bytes than were sent";
+        if (!err && c->comm.nranks == 1)
+            for (int i = 0; i < 32 && !err; ++i)
+                if (back[n + i] != h[i]) err = "the in-place ncclAllGather changed this rank's block";
     } while (false);
     if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
     if (ready) (void)hipEventDestroy(ready);
