@@ -562,7 +562,6 @@ __global__ __launch_bounds__(kSweepRows) void k_amg_sweeps(const AmgSweepArgs<TR
 
 // ---- tail: every level with <= kTailRows rows runs inside ONE workgroup (restrictions, dense coarsest solve,
 // prolongations and smoothing sweeps separated by workgroup barriers) instead of ~4 tiny launches per level.
-constexpr int kTailRows = 4096;
 constexpr int kTailThreads = 1024;
 constexpr int kTailMaxLevels = 8;
 
@@ -912,7 +911,7 @@ static hipError_t estimate_lambda(Ctx* c, AmgHierarchy& H) {
             return e;
     }
     for (size_t l = 0; l < H.xf.size(); ++l) {
-        if (l > 0 && H.lv[l].n <= 4096) break;
+        if (l > 0 && H.lv[l].n <= kTailRows) break;
         const DevSell A = level_sell(c, H, l);
         const float* vals = l == 0 ? H.top_vals : H.lv[l].vals;
         const float* dinv = l == 0 ? H.top_dinv : H.lv[l].dinv;
@@ -1632,7 +1631,7 @@ int amg_setup_distributed(Ctx* c, std::string& err) {
         plans.emplace_back();
         // first sweep on the A*P operator (like the single-GPU hierarchy), except towards a shared dense level, whose
         // solve leaves only this subdomain's rows of the correction behind
-        plans.back().with_ap = !next_dense && Af->n_rows > 4096;
+        plans.back().with_ap = !next_dense && Af->n_rows > kTailRows;
         const int32_t ncols = glob_cols ? offs[R] : (int32_t)(nc_own + cghost);
         std::string perr;
         if (next_rep) {

@@ -600,7 +600,7 @@ std::string build_amg_levels(const SellPattern& A0, const std::vector<int32_t>& 
         colmap.assign(Af->n_cols, -1);
         std::copy(agg.begin(), agg.end(), colmap.begin());
         const bool dense = nc <= coarsest;
-        out.back().with_ap = Af->n_rows > 4096;  // levels handled by launches (the one-workgroup tail prolongates)
+        out.back().with_ap = Af->n_rows > kTailRows;  // levels handled by launches (the one-workgroup tail prolongates)
         std::vector<int32_t> kr;
         std::string err = dense ? coarsen(*Af, agg, colmap, nc, nc, true, out.back())
                                 : coarsen_sorted(*Af, agg, colmap, nc, out.back(), kr);

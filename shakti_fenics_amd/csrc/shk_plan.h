@@ -17,6 +17,11 @@
 namespace shk {
 
 constexpr int kSlice = 64;  // rows per SELL slice = wavefront width
+// Multigrid levels of at most this many rows run inside ONE workgroup (k_amg_tail: restrictions, sweeps and prolongations
+// separated by workgroup barriers); larger ones by launches, with an A*P operator for their first sweep.  Round 3: 4096 ->
+// 512.  One workgroup walks a level of thousands of rows as a chain of dependent loads -- at 1M DOF the tail (one level
+// of 3 905 rows) took 50 us per cycle, a quarter of the step -- where the fused four-sweep launch (k_amg_sweeps) takes ~10.
+constexpr int kTailRows = 512;
 constexpr int kBlkDesc = 12;               // ints per assembly-block descriptor (10 used, 48-byte stride)
 constexpr uint32_t kSrcNone = 0x3FFu;      // slotsrc: cell slot meaning "no source"
 constexpr uint32_t kSrcEmpty = (kSrcNone << 4) | (kSrcNone << 18);   // a slot without sources, Dirichlet code 0
