@@ -148,7 +148,8 @@ static hipError_t upload_sweep_plan(Ctx* c, const SellPattern& A, const SellPatt
     if (!tunables().amg_fused_sweeps || AP.n_rows != A.n_rows) return hipSuccess;
     // the fused launch pays where a sweep is launch-bound; a level too large for that keeps its streaming sweeps
     // (measured at 10M rows, us per cycle in four launches / in one: level 5 of 9.8k rows 26 / 14, level 4 of 39k 26 / 16,
-    //  level 3 of 156k 31 / 22, level 2 of 625k 51 / 63, level 1 of 2.5M 142 / 223: SHK_AMG_FUSED_ROWS = 200 000)
+    //  level 3 of 156k 31 / 22, level 2 of 625k 51 / 63, level 1 of 2.5M 142 / 223; at 1M rows, level 1 of 250k 33 / 31:
+    //  SHK_AMG_FUSED_ROWS = 320 000)
     if (A.n_rows > tunables().amg_fused_rows) return hipSuccess;
     SweepPlan P;
     if (!build_sweep_plan(A, AP, P).empty() || P.nblk == 0) return hipSuccess;   // no plan: one launch per sweep

@@ -34,7 +34,7 @@ struct Tunables {
     int amg_lambda_period = 4;    // SHK_AMG_LAMBDA_PERIOD  dense refreshes between renewals of the spectral estimates
     bool fused_restrict = true;   // SHK_FUSED_RESTRICT  0: one launch per restriction
     bool amg_fused_sweeps = true; // SHK_AMG_FUSED_SWEEPS  0: one launch per smoothing sweep on the small levels
-    int64_t amg_fused_rows = 200000;   // SHK_AMG_FUSED_ROWS  largest level (rows) whose four sweeps run in one launch
+    int64_t amg_fused_rows = 320000;   // SHK_AMG_FUSED_ROWS  largest level (rows) whose four sweeps run in one launch
     double amg_w1 = 0.0, amg_w2 = 0.0;   // SHK_AMG_W1 / W2  absolute dampings of the two finest-level sweeps
     int amg_halo_levels = -1;     // SHK_AMG_HALO_LEVELS  decomposed levels whose sweeps see their neighbours (-1 = all)
     int64_t amg_rep_rows = -1;    // SHK_AMG_REP_ROWS global size from which the coarse levels are replicated (-1 = default)
