@@ -508,6 +508,7 @@ struct Ctx {
     int n_guess[kWarmIts] = {};
     double *d_part_w = nullptr, *d_red_w = nullptr;   // kWarmDots partial arrays / all-reduced scalars
     int warm_its = kWarmIts;
+    double* pending_keep = nullptr;   // where the Newton update that follows a solve also stores its solution (warm start)
     // multigrid preconditioner (empty when unavailable: subdomain contexts, tiny meshes)
     AmgHierarchy amg_local, amg_dist;
     AmgHierarchy* amg = nullptr;    // the active one when use_amg

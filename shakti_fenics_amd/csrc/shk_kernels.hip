@@ -643,19 +643,23 @@ hipError_t krylov_iteration(Ctx* c, int it) {
 __global__ __launch_bounds__(kBlock) void k_newton_update(int64_t n, double relax, int apply, int unscale,
                                                           const double* __restrict__ y,
                                                           const double* __restrict__ dinv, double* __restrict__ dx,
-                                                          double* __restrict__ N) {
+                                                          double* __restrict__ N, double* __restrict__ keep) {
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        const double d = unscale ? y[i] * dinv[i] : y[i];
+        const double yi = y[i];
+        const double d = unscale ? yi * dinv[i] : yi;
         dx[i] = d;
         if (apply) N[i] -= relax * d;
+        if (keep) keep[i] = yi;   // the solution in the solver's own scaling: a starting guess of the next steps' solves
     }
 }
 
 void launch_newton_update(Ctx* c, bool apply) {
     PhaseTimer t(c, SHK_PH_OTHER);
-    note_bytes(c, (apply ? 32.0 : 16.0) * (double)c->n_own + (c->use_amg ? 0.0 : 8.0 * (double)c->n_own));
+    double* keep = c->pending_keep;
+    c->pending_keep = nullptr;
+    note_bytes(c, (apply ? 32.0 : 16.0) * (double)c->n_own + (c->use_amg ? 0.0 : 8.0 * (double)c->n_own) + (keep ? 8.0 * (double)c->n_own : 0.0));
     hipLaunchKernelGGL(k_newton_update, dim3(c->grid), dim3(kBlock), 0, c->stream, c->n_own, c->params.newton_relax,
-                       apply ? 1 : 0, c->use_amg ? 0 : 1, c->d_ytot, c->d_dinv, c->f[SHK_DX], c->f[SHK_N]);
+                       apply ? 1 : 0, c->use_amg ? 0 : 1, c->d_ytot, c->d_dinv, c->f[SHK_DX], c->f[SHK_N], keep);
 }
 
 // ------------------------------------------------------------------ explicit updates (R6-R8)
