@@ -21,6 +21,7 @@ if [ "$1" = "pmc" ]; then
   w=$(ls $out/pmc_WRITE_SIZE/*/*counter_collection.csv | head -1)
   v=$(ls $out/pmc_VALU/*/*counter_collection.csv | head -1)
   python tools/pmc_to_json.py $f $w $((8 * slots)) $out/pmc_traffic_c4_10m.json $v > $out/pmc_to_json.log
+  cp $out/pmc_traffic_c4_10m.json profiles/pmc_traffic_c4_10m.json   # so that a bench leg of the same call finds it
   rm -rf $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmc_VALU
   tail -5 $out/pmc_to_json.log
 else
