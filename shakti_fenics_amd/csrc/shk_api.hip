@@ -399,6 +399,7 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
     c->warm_its = std::max(1, std::min(T.warm_its, (int)Ctx::kWarmIts));   // experiments
     if (P.verts_max > kAsmVertsMax) { delete c; return fail("an assembly block touches more than 768 vertices (degenerate mesh?)"); }
     c->asm_lds = assemble_lds_bytes(P, &c->asm_region_a);
+    c->asm_lds_res = assemble_lds_bytes(P, &c->asm_region_a_res, true);
     if (c->asm_lds > 160 * 1024) { delete c; return fail("assembly LDS budget exceeds 160 KiB"); }
     auto bail = [&](hipError_t e, const char* what) {
         std::string m = std::string(what) + ": " + hipGetErrorString(e);

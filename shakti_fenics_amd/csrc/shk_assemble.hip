@@ -238,13 +238,16 @@ __device__ __forceinline__ void cell_tensor(const AsmArgs& a, const double* __re
 
 // T threads per workgroup; NQ / NP: points of the two rules when they are the built-in ones (15 / 7: loops fully
 // unrolled), 0 = run-time counts (a user table from shk_set_quadrature, or Glen's n != 3).
+// (the residual-only instance stages 3 instead of 12 tensor entries per cell and needs 165 registers: three workgroups
+//  per CU instead of two -- its LDS region is sized separately, Ctx::asm_lds_res)
 template <int T, int NQ, int NP, bool JAC = true>
-__global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) {
+__global__ __launch_bounds__(T, (JAC || NQ == 0) ? SHK_ASM_WAVES : SHK_ASM_WAVES + 1) void k_assemble(const AsmArgs a) {
     constexpr int R = (kAsmCellsMax + T - 1) / T;   // cells per thread
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int E = a.cells_max, V = a.verts_max;
     double* fld = reinterpret_cast<double*>(smem);                  // [13][V] staged fields ...
     double* et = fld;                                               // ... later [12][E] element tensors (same region)
+    constexpr int kF = JAC ? 9 : 0;                                 // tensor row of the element residual (residual-only: [3][E])
     QPoint* qk = reinterpret_cast<QPoint*>(smem + a.lds_region_a);
     QPoint* qp = qk + kMaxQuad;
     int* sp = reinterpret_cast<int*>(qp + kMaxQuad);                // [slices_max+1] SELL ptr of owned slices
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
                 for (int k = 0; k < 9; ++k) et[k * E + t] = out[r].K[k];
             }
 #pragma unroll
-            for (int k = 0; k < 3; ++k) et[(9 + k) * E + t] = out[r].F[k];
+            for (int k = 0; k < 3; ++k) et[(kF + k) * E + t] = out[r].F[k];
         }
     }
     __syncthreads();
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(T, SHK_ASM_WAVES) void k_assemble(const AsmArgs a) 
         const int kb = ip[i] - ip0, ke = ip[i + 1] - ip0;
         for (int q = kb; q < ke; ++q) {
             const int code = ic[q];
-            sum += tensor(9 + (code & 3), code >> 2);
+            sum += tensor(kF + (code & 3), code >> 2);
         }
         if (bcf[i]) sum = a.fld[0][v] - a.bc_value;  // set_bc(b, bcs, x, -1): F = N - g
         a.F[v] = sum;
@@ -442,7 +445,7 @@ static void fill_asm_args(Ctx* c, double dt, AsmArgs& a) {
     a.incptr = c->d_incptr; a.inccode = c->d_inccode;
     a.cells_max = c->plan.cells_max; a.slices_max = c->plan.slices_max; a.verts_max = c->plan.verts_max;
     a.inc_max = c->plan.max_inc_per_block;
-    a.lds_region_a = (int)c->asm_region_a;
+    a.lds_region_a = (int)c->asm_region_a;   // (launch_assemble overrides it for the residual-only instance)
 #ifdef SHK_EXPERIMENTS
     a.ablate = tunables().asm_ablate;   // probe builds only
 #endif
@@ -453,9 +456,9 @@ static void fill_asm_args(Ctx* c, double dt, AsmArgs& a) {
 }
 
 // LDS of one assembly workgroup: region A (staged fields, then the element tensors) + tables
-size_t assemble_lds_bytes(const HostPlan& P, size_t* region_a) {
+size_t assemble_lds_bytes(const HostPlan& P, size_t* region_a, bool residual_only) {
     const size_t E = P.cells_max, S = P.slices_max, V = P.verts_max;
-    size_t ra = std::max((size_t)kAsmFields * V, 12 * E) * sizeof(double);
+    size_t ra = std::max((size_t)kAsmFields * V, (residual_only ? 3 : 12) * E) * sizeof(double);
     ra = (ra + 15) & ~size_t(15);
     if (region_a) *region_a = ra;
     size_t lds = ra + 2 * kMaxQuad * sizeof(QPoint) + (S + 1) * sizeof(int) + (S * kSlice + 1) * sizeof(int) +
@@ -471,8 +474,9 @@ void launch_assemble(Ctx* c, double dt, bool residual_only) {
     const bool builtin = a.quad.nq == 15 && a.qpoly.nq == 7;
     if (residual_only) {   // no plan words, no values, no 1/diag
         note_bytes(c, c->asm_bytes - 12.0 * (double)c->slots - 8.0 * (double)c->n_own);
-        if (builtin) launch_phase(c, SHK_PH_ASSEMBLE, k_assemble<kBlock, 15, 7, false>, dim3(c->nblk), dim3(kBlock), c->asm_lds, a);
-        else launch_phase(c, SHK_PH_ASSEMBLE, k_assemble<kBlock, 0, 0, false>, dim3(c->nblk), dim3(kBlock), c->asm_lds, a);
+        a.lds_region_a = (int)c->asm_region_a_res;
+        if (builtin) launch_phase(c, SHK_PH_ASSEMBLE, k_assemble<kBlock, 15, 7, false>, dim3(c->nblk), dim3(kBlock), c->asm_lds_res, a);
+        else launch_phase(c, SHK_PH_ASSEMBLE, k_assemble<kBlock, 0, 0, false>, dim3(c->nblk), dim3(kBlock), c->asm_lds_res, a);
         return;
     }
     note_bytes(c, c->asm_bytes);

@@ -495,6 +495,7 @@ struct Ctx {
     int nblk = 0;
     int64_t cells_staged = 0;  // cells computed per assembly incl. those shared between blocks
     size_t asm_lds = 0, asm_region_a = 0;
+    size_t asm_lds_res = 0, asm_region_a_res = 0;   // the residual-only instance: 3 instead of 12 staged tensor entries per cell
     double *d_F = nullptr, *d_vals = nullptr, *d_vals_s = nullptr, *d_dinv = nullptr;
     float *d_vals32 = nullptr, *d_dinv32 = nullptr;   // float copies read by the multigrid preconditioner
     // Krylov vectors
@@ -584,7 +585,7 @@ int set_error(const std::string& msg);
 
 // launchers (shk_kernels.hip)
 hipError_t prepare_kernels(Ctx* c);
-size_t assemble_lds_bytes(const HostPlan& P, size_t* region_a);
+size_t assemble_lds_bytes(const HostPlan& P, size_t* region_a, bool residual_only = false);
 void launch_assemble(Ctx* c, double dt, bool residual_only = false);
 void launch_slot_bc(Ctx* c);
 void launch_scale(Ctx* c);
