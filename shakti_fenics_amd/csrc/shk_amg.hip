@@ -585,23 +585,25 @@ struct TailArgs {
 
 // x[i] = sum_j inv[(row0 + i) * ncols + j] * r[j]: one wave per row, over the whole chip (the one-workgroup
 // tail would read a 1024 x 1024 inverse through a single CU: 150 us instead of 5).
-template <class TR>
-__global__ __launch_bounds__(kBlock) void k_dense_gemv(int n, int row0, int ncols, const double* __restrict__ inv,
+// TI: the inverse as it is applied -- double for a shared dense level of a decomposed hierarchy, a float copy for a
+// hierarchy's own dense level (the cycle is a float preconditioner; 2441^2 entries: 48 -> 24 MB per application)
+template <class TR, class TI = double>
+__global__ __launch_bounds__(kBlock) void k_dense_gemv(int n, int row0, int ncols, const TI* __restrict__ inv,
                                                        const TR* __restrict__ r, float* __restrict__ x,
                                                        const int* __restrict__ done) {
     if (*done) return;
     const int lane = threadIdx.x & 63;
     for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += gridDim.x * 4) {
-        const double* row = inv + (size_t)(row0 + i) * ncols;
+        const TI* row = inv + (size_t)(row0 + i) * ncols;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
         int j = lane;
         for (; j + 192 < ncols; j += 256) {  // four independent streams per lane
-            a0 += row[j] * (double)r[j];
-            a1 += row[j + 64] * (double)r[j + 64];
-            a2 += row[j + 128] * (double)r[j + 128];
-            a3 += row[j + 192] * (double)r[j + 192];
+            a0 += (double)row[j] * (double)r[j];
+            a1 += (double)row[j + 64] * (double)r[j + 64];
+            a2 += (double)row[j + 128] * (double)r[j + 128];
+            a3 += (double)row[j + 192] * (double)r[j + 192];
         }
-        for (; j < ncols; j += 64) a0 += row[j] * (double)r[j];
+        for (; j < ncols; j += 64) a0 += (double)row[j] * (double)r[j];
         double acc = (a0 + a1) + (a2 + a3);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
@@ -1070,8 +1072,11 @@ hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense, bool d
                                    X.glist, fine, H.cdense);
                 if (X.n_coarse <= 64)
                     hipLaunchKernelGGL(k_dense_invert, dim3(1), dim3(kBlock), 0, c->stream, X.n_coarse, H.cdense, H.cinv);
-                else if (refresh_dense)
+                else if (refresh_dense) {
                     dense_invert_big(c, X.n_coarse, H.cdense, H.cinv, H.gj);
+                    if (H.cinv32)   // the copy the cycle applies
+                        hipLaunchKernelGGL(k_narrow, dim3(small_grid(ns)), dim3(kBlock), 0, c->stream, ns, (const double*)H.cinv, H.cinv32);
+                }
                 H.dense_valid = true;
             }
         } else {
@@ -1288,7 +1293,7 @@ static hipError_t amg_vcycle_t(Ctx* c, AmgHierarchy& H, const TR* rin, float* zo
             if ((e = allreduce_buffer(c, H.cglob, H.cglob, (size_t)H.n_glob)) != hipSuccess) return e;
             PhaseTimer t(c, SHK_PH_AMG_DENSE);
             if (!ta.dense_in_tail)
-                hipLaunchKernelGGL(k_dense_gemv<double>, dim3(gemv_grid), dim3(kBlock), 0, c->stream, ta.n_c, ta.row0,
+                hipLaunchKernelGGL((k_dense_gemv<double, double>), dim3(gemv_grid), dim3(kBlock), 0, c->stream, ta.n_c, ta.row0,
                                    ta.ncols, ta.inv, (const double*)H.cglob, ta.cx, done);
             if (ta.nlev > 0 || ta.dense_in_tail) hipLaunchKernelGGL(k_amg_tail<2>, dim3(1), dim3(kTailThreads), 0, c->stream, ta);
         } else if (ta.dense_in_tail) {
@@ -1301,9 +1306,13 @@ static hipError_t amg_vcycle_t(Ctx* c, AmgHierarchy& H, const TR* rin, float* zo
             }
             {
                 PhaseTimer t(c, ph(SHK_PH_AMG_DENSE));
-                note_bytes(c, 8.0 * (double)ta.n_c * ta.ncols + 4.0 * (double)(ta.n_c + ta.ncols));
-                hipLaunchKernelGGL(k_dense_gemv<float>, dim3(gemv_grid), dim3(kBlock), 0, c->stream, ta.n_c, ta.row0, ta.ncols,
-                                   ta.inv, (const float*)H.cr, ta.cx, done);
+                note_bytes(c, (H.cinv32 ? 4.0 : 8.0) * (double)ta.n_c * ta.ncols + 4.0 * (double)(ta.n_c + ta.ncols));
+                if (H.cinv32)
+                    hipLaunchKernelGGL((k_dense_gemv<float, float>), dim3(gemv_grid), dim3(kBlock), 0, c->stream, ta.n_c, ta.row0,
+                                       ta.ncols, (const float*)H.cinv32, (const float*)H.cr, ta.cx, done);
+                else
+                    hipLaunchKernelGGL((k_dense_gemv<float, double>), dim3(gemv_grid), dim3(kBlock), 0, c->stream, ta.n_c, ta.row0,
+                                       ta.ncols, ta.inv, (const float*)H.cr, ta.cx, done);
             }
             if (ta.nlev > 0) {
                 PhaseTimer t(c, ph(SHK_PH_AMG_COARSE));

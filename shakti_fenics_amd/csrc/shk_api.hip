@@ -293,6 +293,7 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
             const size_t cols = (size_t)LP.n_coarse_cols;
             if ((e = dev_alloc(c, &H.cdense, rows * cols)) != hipSuccess) return e;
             if ((e = dev_alloc(c, &H.cinv, rows * cols)) != hipSuccess) return e;
+            if (!H.distributed && cols > 128 && (e = dev_alloc(c, &H.cinv32, rows * cols)) != hipSuccess) return e;
             if ((e = dev_alloc(c, &H.cr, std::max<size_t>(64, std::max(rows, cols)))) != hipSuccess) return e;
             if ((e = dev_alloc(c, &H.cx, std::max<size_t>(64, rows))) != hipSuccess) return e;
             if ((e = dev_alloc(c, &H.cglob, std::max<size_t>(64, std::max(rows, cols)))) != hipSuccess) return e;

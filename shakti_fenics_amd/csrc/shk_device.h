@@ -395,7 +395,8 @@ struct AmgHierarchy {
     int64_t ap_nnz0 = 0;             // stored entries of the finest level's A*P operator
     int32_t n_glob = 0, offset = 0;  // dense coarsest operator: n_glob x n_glob, my rows start at `offset`
     float *x0 = nullptr, *x1 = nullptr, *x2 = nullptr, *cr = nullptr, *cx = nullptr;   // x1, x2: eigenvalue-estimate scratch (finest level)
-    double *cdense = nullptr, *cinv = nullptr, *cglob = nullptr;   // the coarsest solve stays in double
+    double *cdense = nullptr, *cinv = nullptr, *cglob = nullptr;   // the coarsest operator and its inverse are built in double
+    float* cinv32 = nullptr;     // ... and applied from a float copy by a hierarchy's own dense level (> 128 rows)
     double* gj = nullptr;        // 2 * 1024 doubles of Gauss-Jordan scratch
     // Replicated coarse part of a decomposed hierarchy: from the first level whose GLOBAL size is small enough, the
     // level is gathered (one all-reduce of the right-hand side per cycle) and the rest of the cycle runs on every
