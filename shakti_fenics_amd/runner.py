@@ -55,6 +55,7 @@ def _pmc_traffic(config, nv):
         out["assemble"] = k["assemble"]["hbm_bytes"]
         out["assemble_valu_insts"] = k["assemble"].get("valu_wave_insts")
         out["assemble_wait_any_frac"] = k["assemble"].get("wait_any_frac")
+        out["assemble_residual_valu_insts"] = k.get("assemble_residual_only", {}).get("valu_wave_insts")
     return out
 
 
@@ -164,13 +165,24 @@ class SingleRunner:
         legs = {k: leg(k) for k in ("spmv", "assemble", "amg_fine", "amg_first") if ph[k]["launches"]}
         if "assemble" in legs:
             a = legs["assemble"]
-            valu = pmc.get("assemble_valu_insts")
-            floor_ms = valu * 4.0 / (1024 * 2.4e9) * 1e3 if valu else None   # 4 cycles per fp64 wave-instruction, 1024 SIMDs
-            a.update(bound="fp64 valu", hbm_frac=a["frac"], valu_wave_insts=valu, valu_issue_floor_ms=floor_ms,
-                     frac=(floor_ms / a["avg_launch_ms"]) if floor_ms else None,
+            # the two instances apart, each against ITS ceiling (the profiled step mixes them: two full passes and, when the
+            # last Newton iteration was predicted, one residual-only pass): a few back-to-back launches of each
+            c.assemble(self.dt)
+            inst = {"full": (c.time_kernel("assemble", 3, self.dt), pmc.get("assemble_valu_insts")),
+                    "residual_only": (c.time_assemble_residual(3, self.dt), pmc.get("assemble_residual_valu_insts"))}
+            c.assemble(self.dt)
+            per = {}
+            for name, (ms, valu) in inst.items():
+                floor_ms = valu * 4.0 / (1024 * 2.4e9) * 1e3 if valu else None   # 4 cycles per fp64 wave-instruction, 1024 SIMDs
+                per[name] = {"avg_launch_ms": ms, "valu_wave_insts": valu, "valu_issue_floor_ms": floor_ms,
+                             "frac": (floor_ms / ms) if floor_ms and ms > 0 else None}
+            a.update(bound="fp64 valu", hbm_frac=a["frac"], frac=per["full"]["frac"], instances=per,
+                     valu_wave_insts=per["full"]["valu_wave_insts"], valu_issue_floor_ms=per["full"]["valu_issue_floor_ms"],
+                     wait_any_frac=pmc.get("assemble_wait_any_frac"),
                      bound_note="k_assemble is bound by fp64 vector issue, not HBM: frac = (VALU wave-instructions x 4 cycles / "
-                                "(1024 SIMDs x 2.4 GHz)) / measured time; hbm_frac = needed bytes / time / 8 TB/s"
-                                + ("" if floor_ms else " (no counter file for these kernel sources: frac is null)"))
+                                "(1024 SIMDs x 2.4 GHz)) / time of the FULL instance launched back to back; `instances` has the "
+                                "residual-only instance too; hbm_frac = needed bytes / mean time of the profiled step's passes / 8 TB/s"
+                                + ("" if per["full"]["frac"] else " (no counter file for these kernel sources: frac is null)"))
         dom = max((k for k in legs if k != "assemble"), key=lambda k: ph[k]["ms"])
         d = legs[dom]
         # whole step: every launch the profiled step made
