@@ -158,6 +158,12 @@ int shk_comm_selftest(shk_ctx* ctx);
  * those of the subdomain: one rank of a P-way decomposition can be timed alone on one GPU (tools/scaling_model.py).
  * shk_step / shk_newton_solve report what they computed; nothing in the product path turns this on. */
 int shk_comm_set_timing_only(shk_ctx* ctx, int32_t on);
+/* Time `reps` back-to-back RCCL message rounds of one kind on the context's stream: kind 0 = grouped ncclSend + ncclRecv
+ * of n doubles with the neighbouring rank (rank ^ 1; the rank itself on a one-rank communicator), 1 = ncclAllReduce of n
+ * doubles, 2 = in-place ncclAllGather of n bytes per rank.  Microseconds per round.  On a one-GPU box (one-rank
+ * communicator) this is the software floor of a round -- launch + protocol, no link -- i.e. the lower bound of the
+ * message cost the strong-scaling model of profiles/r03_scaling_model.md leaves free. */
+int shk_comm_time_round(shk_ctx* ctx, int32_t kind, int64_t n, int32_t reps, double* us_per_round);
 /* Start-up check of the reduction path (either transport): value[0] is summed over the subdomains through the SAME
  * all-reduce the Krylov loop uses, on the context's stream, and the host wait goes through the RCCL deadline
  * (SHK_COMM_TIMEOUT_S): a mis-wired communicator fails here with an error instead of hanging the first solve.  The ghost

@@ -67,7 +67,7 @@ EXPORTS = (
     "shk_assemble", "shk_get_residual", "shk_csr_nnz", "shk_get_csr", "shk_linear_solve", "shk_spmv",
     "shk_newton_solve", "shk_update_explicit", "shk_step", "shk_sync", "shk_profile_enable",
     "shk_profile_read", "shk_time_kernel", "shk_time_assemble_residual", "shk_solver_stats", "shk_plan_stats", "shk_set_halo", "shk_comm_unique_id",
-    "shk_comm_init_rccl", "shk_comm_init_callbacks", "shk_comm_selftest", "shk_comm_set_timing_only", "shk_comm_mark_stalled", "shk_comm_allreduce_check", "shk_env_overrides", "shk_tunable_set", "shk_comm_stats", "shk_comm_overlap", "shk_halo_update", "shk_interp_regular_grid",
+    "shk_comm_init_rccl", "shk_comm_init_callbacks", "shk_comm_selftest", "shk_comm_set_timing_only", "shk_comm_mark_stalled", "shk_comm_allreduce_check", "shk_comm_time_round", "shk_env_overrides", "shk_tunable_set", "shk_comm_stats", "shk_comm_overlap", "shk_halo_update", "shk_interp_regular_grid",
     "shk_points_in_polygon",
 )
 
@@ -130,6 +130,7 @@ def load():
         "shk_comm_set_timing_only": ([vp, i32], C.c_int),
         "shk_comm_mark_stalled": ([vp], C.c_int),
         "shk_comm_allreduce_check": ([vp, P(dbl)], C.c_int),
+        "shk_comm_time_round": ([vp, i32, i64, i32, P(dbl)], C.c_int),
         "shk_env_overrides": ([C.c_char_p, i64], i64),
         "shk_tunable_set": ([C.c_char_p, C.c_char_p], C.c_int),
         "shk_interp_regular_grid": ([C.c_int, i64, vp, vp, i64, i64, vp, vp, vp, i32, vp], C.c_int),
@@ -414,6 +415,14 @@ class ShaktiHip:
         v = C.c_double(float(value))
         self._check(self.lib.shk_comm_allreduce_check(self._h, C.byref(v)))
         return v.value
+
+    def comm_time_round(self, kind: str, n: int, reps: int = 200) -> float:
+        """Microseconds per RCCL round of `kind` ("sendrecv" of n doubles, "allreduce" of n doubles, "allgather" of n bytes
+        per rank), `reps` back to back on the context's stream."""
+        us = C.c_double()
+        self._check(self.lib.shk_comm_time_round(self._h, ("sendrecv", "allreduce", "allgather").index(kind), int(n), int(reps),
+                                                 C.byref(us)))
+        return us.value
 
     def comm_mark_stalled(self):
         self._check(self.lib.shk_comm_mark_stalled(self._h))

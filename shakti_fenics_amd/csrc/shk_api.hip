@@ -1099,6 +1099,17 @@ int shk_comm_set_timing_only(shk_ctx* ctx, int32_t on) {
     return 0;
 }
 
+int shk_comm_time_round(shk_ctx* ctx, int32_t kind, int64_t n, int32_t reps, double* us_per_round) {
+    CHECK_CTX(ctx);
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!us_per_round || kind < 0 || kind > 2) return fail("bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    const double us = rccl_time_round(c, kind, n, reps);
+    if (us < 0.0) return fail("no RCCL communicator on this context (or the timed rounds failed)");
+    *us_per_round = us;
+    return 0;
+}
+
 int shk_comm_allreduce_check(shk_ctx* ctx, double* value) {
     CHECK_CTX(ctx);
     Ctx* c = reinterpret_cast<Ctx*>(ctx);

@@ -153,6 +153,48 @@ const char* rccl_selftest(Ctx* c) {
     return err;
 }
 
+// Time `reps` back-to-back message rounds of one kind on the context's stream (hipEvents), on whatever communicator the
+// context has -- with the one-rank communicator of a one-GPU box the peer is the rank itself, so the result is the
+// SOFTWARE FLOOR of a round (RCCL's kernel launch + protocol, no link): the lower bound of the scaling model's free
+// parameter.  kind 0: grouped ncclSend + ncclRecv of n doubles; 1: ncclAllReduce of n doubles; 2: in-place ncclAllGather
+// of n bytes per rank.  Returns microseconds per round, or < 0.
+double rccl_time_round(Ctx* c, int kind, int64_t n, int reps) {
+    if (c->comm.kind != Comm::RCCL || !c->comm.nccl || reps < 1 || n < 1) return -1.0;
+    ncclComm_t comm = reinterpret_cast<ncclComm_t>(c->comm.nccl);
+    const int me = c->comm.rank, R = c->comm.nranks;
+    const size_t bytes = (size_t)std::max<int64_t>(n, 1) * sizeof(double) * 2 * (size_t)std::max(R, 1);
+    double* d = nullptr;
+    if (hipMalloc((void**)&d, bytes) != hipSuccess) return -1.0;
+    (void)hipMemsetAsync(d, 0, bytes, c->stream);
+    hipEvent_t a = nullptr, b = nullptr;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    auto once = [&]() {
+        if (kind == 0) {
+            const int peer = R > 1 ? (me ^ 1) < R ? (me ^ 1) : me : me;
+            g_rccl.GroupStart();
+            g_rccl.Send(d, (size_t)n, ncclDouble, peer, comm, c->stream);
+            g_rccl.Recv(d + n, (size_t)n, ncclDouble, peer, comm, c->stream);
+            g_rccl.GroupEnd();
+        } else if (kind == 1) {
+            g_rccl.AllReduce(d, d, (size_t)n, ncclDouble, ncclSum, comm, c->stream);
+        } else {
+            char* blk = reinterpret_cast<char*>(d);
+            g_rccl.AllGather(blk + (size_t)n * me, blk, (size_t)n, ncclChar, comm, c->stream);
+        }
+    };
+    for (int i = 0; i < 3; ++i) once();   // warm
+    (void)hipEventRecord(a, c->stream);
+    for (int i = 0; i < reps; ++i) once();
+    (void)hipEventRecord(b, c->stream);
+    float ms = -1.0f;
+    if (wait_stream(c) == hipSuccess) (void)hipEventElapsedTime(&ms, a, b);
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    (void)hipFree(d);
+    return ms < 0.0f ? -1.0 : 1e3 * (double)ms / reps;
+}
+
 void comm_abort(Ctx* c) {
     if (c->comm.kind == Comm::RCCL && c->comm.nccl) {
         typedef ncclResult_t (*abort_fn)(ncclComm_t);

@@ -612,6 +612,7 @@ const char* rccl_init(Ctx* c, int rank, int nranks, const void* id128);
 void comm_destroy(Ctx* c);
 void comm_abort(Ctx* c);                 // poisoned context: ncclCommAbort if the library has it, else the communicator is leaked
 const char* rccl_selftest(Ctx* c);
+double rccl_time_round(Ctx* c, int kind, int64_t n, int reps);
 hipError_t halo_exchange(Ctx* c, double* vec);                       // level 0
 hipError_t halo_exchange_plan(Ctx* c, const HaloPlan& P, double* vec);
 hipError_t halo_exchange_plan_f32(Ctx* c, const HaloPlan& P, float* vec);
