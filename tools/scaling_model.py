@@ -293,6 +293,21 @@ def report(res, a):
           "| message cost per round | " + " | ".join(f"P = {P}: ms/step (speedup)" for P in Ps) + " |", "|---|" + "---|" * len(Ps)]
     for m_us, row in res["model"].items():
         L.append(f"| {m_us} us | " + " | ".join(f"{row[P]['ms_per_step']:.1f} ({row[P]['speedup']:.2f}x)" for P in Ps) + " |")
+    # what bounds the curve: the terms of a Krylov iteration that do NOT shrink with P
+    one, last = runs["1"], runs[Ps[-1]]
+    shrink = last["amg_fine"] + last["amg_first"] + last["spmv"] + last["vector"] + sum(last[f"amg_l{l}"] for l in range(1, 9))
+    fixed = last["amg_rep"] + last["amg_restrict"] + last["amg_dense"] + last["amg_other"] + last["halo"]
+    rounds = last["rounds"] + last["allreduces"] + last["allgathers"]
+    L += ["", f"## What binds it at P = {Ps[-1]} (ms per Krylov iteration; one GPU: {one['kernel_ms']:.3f})", "",
+          f"* work that shrinks with P (finest level, products, vector kernels, decomposed coarse levels): **{shrink:.3f}** "
+          f"= {one['kernel_ms'] / shrink:.1f}x below one GPU's iteration if it were all there is;",
+          f"* work that does not (replicated levels {last['amg_rep']:.3f}, restrictions + dense solve "
+          f"{last['amg_restrict'] + last['amg_dense'] + last['amg_other']:.3f}, pack / unpack kernels {last['halo']:.3f}): **{fixed:.3f}**;",
+          f"* {rounds:.1f} message rounds: **{rounds * 0.010:.3f} / {rounds * 0.020:.3f} / {rounds * 0.030:.3f}** at 10 / 20 / 30 us each "
+          "(measured floor of a grouped send + recv round on one GPU, no link crossed: 4.8 us + its pack kernel -- "
+          "`profiles/r03_rccl_round_floor.txt`).",
+          f"* A 6x step would need {one['kernel_ms'] / 6:.3f} ms per iteration: less than the shrinking work plus the replicated levels "
+          f"({shrink + last['amg_rep']:.3f}) before a single message is sent."]
     return L
 
 
