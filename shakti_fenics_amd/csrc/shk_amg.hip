@@ -106,6 +106,41 @@ __global__ __launch_bounds__(kBlock) void k_diag_inv(int32_t n, const int32_t* _
 }
 
 // float copies of the Jacobian and of its inverse diagonal (level 0 of the preconditioner)
+// Smoother copy of a level's values (DevSell::pk): bfloat16, round to nearest even, beside the slot's 16-bit column.
+// The smoothing sweeps stream two thirds of the bytes; what they lose is 2^-9 relative per entry of a preconditioner
+// whose cycle reduces the error by ~0.7: the Krylov iteration counts do not move.
+__device__ __forceinline__ uint32_t bf16_bits(float v) {   // round to nearest even, in the upper half word
+    uint32_t u = __float_as_uint(v);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u & 0xffff0000u;
+}
+// own / own_off: column of row i's own slot = own_off + own[i] (A*P: its aggregate), or i itself (own == nullptr)
+__global__ __launch_bounds__(kBlock) void k_pack_bf16(const DevSell A, const float* __restrict__ vals, uint32_t* __restrict__ pk,
+                                                      const int32_t* __restrict__ own, int32_t own_off) {
+    const int lane = threadIdx.x & 63;
+    for (int s = 4 * blockIdx.x + wave_index(); s < A.nslice; s += 4 * gridDim.x) {
+        const SellMeta m = sell_meta(A, s);
+        if (m.cb < 0) continue;
+        const int row = min(s * kSlice + lane, A.n_rows - 1);
+        const uint32_t mine = (uint32_t)((own ? own_off + own[row] : row) - m.cb);
+        float sum = 0.0f;
+        int kd = -1;
+        for (int k = 0; k < m.width; ++k) {
+            const float v = vals[m.base + k * kSlice + lane];
+            const uint32_t col = A.col16[m.p16 + k * kSlice + lane];
+            sum += v;
+            if (col == mine && v != 0.0f) kd = k;
+            pk[m.p16 + k * kSlice + lane] = bf16_bits(v) | col;
+        }
+        if (kd >= 0) pk[m.p16 + kd * kSlice + lane] = bf16_bits(sum) | mine;
+    }
+}
+static void launch_pack(Ctx* c, const DevSell& A, const float* vals, int64_t slots16, const int32_t* own = nullptr, int32_t own_off = 0) {
+    if (!A.pk) return;
+    note_bytes(c, 10.0 * (double)slots16);
+    hipLaunchKernelGGL(k_pack_bf16, dim3(std::min((A.nslice + 3) / 4, 4096)), dim3(kBlock), 0, c->stream, A, vals,
+                       const_cast<uint32_t*>(A.pk), own, own_off);
+}
 __global__ __launch_bounds__(kBlock) void k_narrow(int64_t n, const double* __restrict__ a, float* __restrict__ b) {
     const int64_t n2 = n >> 1;
     typedef double dvec2 __attribute__((ext_vector_type(2)));
@@ -347,7 +382,7 @@ struct AmgSmoothArgs {
     SplitSell split;        // PASS 1, 2 only (finest level of a decomposed mesh)
 };
 // FINE only gives the finest level its own symbol, so that profilers report its launches separately
-template <bool FINE, class TX, class TR, class TO, int PASS = 0>   // PASS: SplitSell (shk_device.h)
+template <bool FINE, class TX, class TR, class TO, int PASS = 0, bool PK = false>   // PASS: SplitSell; PK: DevSell::pk (shk_device.h)
 __global__ __launch_bounds__(kBlock) void k_amg_post(const AmgSmoothArgs<TX, TR, TO> a) {
     if (*a.done) return;
     const int lane = threadIdx.x & 63;
@@ -357,7 +392,7 @@ __global__ __launch_bounds__(kBlock) void k_amg_post(const AmgSmoothArgs<TX, TR,
         const TR rr = a.r[row];
         const float di = a.dinv[row];
         const bool skip = PASS == 1 ? a.split.ghost[s] != 0 : false;
-        const auto sum = sell_row_sum(a.A, m, a.vals, a.x, lane);
+        const auto sum = sell_row_sum_pk<PK>(a.A, m, a.vals, a.x, lane, row, (float)xr);   // (own column = the row)
         if (s * kSlice + lane < a.A.n_rows && !skip) a.xo[row] = (TO)(xr + a.omega * di * (rr - sum));
     };
     if (PASS == 2) {
@@ -412,7 +447,7 @@ struct AmgFirstArgs {
 // GHOSTS: the instance that also fills the ghost columns (decomposed levels with frozen ghosts).  A separate instance
 // because the mere presence of that (zero-trip) loop cost the one-subdomain kernel 25 % (97 -> 121 us at 10M rows: 16 more
 // registers and a differently scheduled slice loop); without it the kernel is the one rounds 1-2 measured.
-template <bool FINE, class TR, bool GHOSTS = false>
+template <bool FINE, class TR, bool GHOSTS = false, bool PK = false>
 __global__ __launch_bounds__(kBlock) void k_amg_first(const AmgFirstArgs<TR> a) {
     if (*a.done) return;
     const int lane = threadIdx.x & 63;
@@ -428,8 +463,9 @@ __global__ __launch_bounds__(kBlock) void k_amg_first(const AmgFirstArgs<TR> a) 
         const int ag = a.agg[row];
         const float rr = (float)a.r[row];
         const float di = a.dinv[row];
-        const float sum = sell_row_sum(a.AP, it.m, a.vals, a.e, lane);
-        if (it.s * kSlice + lane < a.AP.n_rows) a.xo[row] = a.alpha * a.e[a.agg_off + ag] + a.omega * di * (rr - a.alpha * sum);
+        const float eo = a.e[a.agg_off + ag];
+        const float sum = sell_row_sum_pk<PK>(a.AP, it.m, a.vals, a.e, lane, a.agg_off + ag, eo);
+        if (it.s * kSlice + lane < a.AP.n_rows) a.xo[row] = a.alpha * eo + a.omega * di * (rr - a.alpha * sum);
     }
 }
 
@@ -803,6 +839,7 @@ __global__ __launch_bounds__(kBlock) void k_gershgorin(const DevSell A, const fl
 static int small_grid(int64_t n) { return (int)std::min<int64_t>(1024, std::max<int64_t>(1, (n + kBlock - 1) / kBlock)); }
 
 static DevSell level_sell(const Ctx* c, const AmgHierarchy& H, size_t l);
+static DevSell ap_sell(const AmgXfer& X);
 
 // Largest common factor <= 1 of a sweep sequence's dampings w_k = f c_k / lambda such that the sequence's error
 // polynomial  prod_k (1 - w_k t)  stays within [-1, 1] at t = G, an upper bound of the spectrum of D^-1 A (the
@@ -993,7 +1030,7 @@ static void bind_top_to_jacobian(Ctx* c, AmgHierarchy& H) {
     H.topA = c->sell32();
     H.top_vals = c->d_vals32;
     H.top_dinv = c->d_dinv32;
-    H.top_bytes = sell_bytes(c->slots, c->slots16, c->plan.A.nslice, 4);
+    H.top_bytes = amg_sell_bytes(c->slots, c->slots16, c->plan.A.nslice, c->d_pk != nullptr);
 }
 
 hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense, bool decided, bool top_only) {
@@ -1008,6 +1045,7 @@ hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense, bool d
         note_bytes(c, 12.0 * (double)c->slots + 12.0 * (double)c->n_own);
         hipLaunchKernelGGL(k_narrow, dim3(c->grid), dim3(kBlock), 0, c->stream, c->slots, c->d_vals, c->d_vals32);
         hipLaunchKernelGGL(k_narrow, dim3(small_grid(c->n_own)), dim3(kBlock), 0, c->stream, c->n_own, c->d_dinv, c->d_dinv32);
+        launch_pack(c, H.topA, c->d_vals32, c->slots16);
         return hipSuccess;
     }
     // a large dense coarsest inverse (2 launches per pivot) is only rebuilt when asked to: between the Newton
@@ -1033,6 +1071,7 @@ hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense, bool d
         note_bytes(c, 12.0 * (double)c->slots + 12.0 * (double)c->n_own);
         hipLaunchKernelGGL(k_narrow, dim3(c->grid), dim3(kBlock), 0, c->stream, c->slots, c->d_vals, c->d_vals32);
         hipLaunchKernelGGL(k_narrow, dim3(small_grid(c->n_own)), dim3(kBlock), 0, c->stream, c->n_own, c->d_dinv, c->d_dinv32);
+        launch_pack(c, H.topA, c->d_vals32, c->slots16);
     }
     const float* fine = H.top_vals;
     for (size_t l = 0; l < H.xf.size(); ++l) {
@@ -1040,7 +1079,10 @@ hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense, bool d
         // (every finer value is read once by each of the two gather plans: 8 B per list entry)
         note_bytes(c, 8.0 * (double)(X.n_glist + (X.with_ap ? X.ap_n_glist : 0)));
         if (X.with_ap)
+        {
             launch_galerkin<float>(c, 1, X.ap_slots, X.ap_gptr, X.ap_glist, fine, X.ap_vals);
+            launch_pack(c, ap_sell(X), X.ap_vals, X.ap_slots16, X.agg, X.onto_global ? H.rep_row0 : 0);
+        }
         if (X.onto_global) {
             // my rows of the replicated global level -- whole SELL slices, since every subdomain's block is a multiple of
             // 1024 rows: the slots [rep_val_off[me], rep_val_off[me + 1]) of its value array -- written in place (float,
@@ -1082,6 +1124,7 @@ hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense, bool d
         } else {
             AmgLevel& L = H.lv[l + 1];
             launch_galerkin<float>(c, 0, L.slots, X.gptr, X.glist, fine, L.vals);
+            launch_pack(c, level_sell(c, H, l + 1), L.vals, L.slots16);
             hipLaunchKernelGGL(k_diag_inv, dim3(small_grid(L.n)), dim3(kBlock), 0, c->stream, L.n, L.diag_slot, L.vals,
                                L.dinv);
             fine = L.vals;
@@ -1104,8 +1147,13 @@ hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense, bool d
 static DevSell level_sell(const Ctx* c, const AmgHierarchy& H, size_t l) {
     if (l == 0) return H.topA;
     const AmgLevel& L = H.lv[l];
-    return DevSell{L.n, L.n_cols, L.nslice, sell_fits_cache(L.slots, kAmgSlotBytes), L.ptr, L.col, L.rowlen, L.cbase,
-                   L.ptr16, L.col16};
+    return DevSell{L.n, L.n_cols, L.nslice, sell_fits_cache(L.slots, L.pk ? kAmgPackedSlotBytes : kAmgSlotBytes), L.ptr, L.col,
+                   L.rowlen, L.cbase, L.ptr16, L.col16, L.pk};
+}
+// A*P of a transfer: fine rows x coarse columns
+static DevSell ap_sell(const AmgXfer& X) {
+    return DevSell{X.n_fine, X.n_coarse_cols, X.ap_nslice, sell_fits_cache(X.ap_slots, X.ap_pk ? kAmgPackedSlotBytes : kAmgSlotBytes),
+                   X.ap_ptr, X.ap_col, X.ap_rowlen, X.ap_cbase, X.ap_ptr16, X.ap_col16, X.ap_pk};
 }
 
 // first level handled by the single-workgroup tail (levels that exchange ghosts never are)
@@ -1160,8 +1208,13 @@ static void launch_post(Ctx* c, const DevSell& A, const float* vals, const float
     AmgSmoothArgs<TX, TR, TO> a{A, vals, dinv, r, x, xo, w, done};
     const dim3 g(std::min((A.nslice + 3) / 4, 2048));
     note_bytes(c, post_bytes + (double)A.n_rows * (sizeof(TX) + sizeof(TR) + 4 + sizeof(TO)));
-    if (FINE) launch_phase(c, phase, k_amg_post<FINE, TX, TR, TO>, g, dim3(kBlock), 0, a);
-    else hipLaunchKernelGGL((k_amg_post<FINE, TX, TR, TO>), g, dim3(kBlock), 0, c->stream, a);
+    if (FINE) {
+        if (A.pk) launch_phase(c, phase, k_amg_post<FINE, TX, TR, TO, 0, true>, g, dim3(kBlock), 0, a);
+        else launch_phase(c, phase, k_amg_post<FINE, TX, TR, TO>, g, dim3(kBlock), 0, a);
+    } else {
+        if (A.pk) hipLaunchKernelGGL((k_amg_post<FINE, TX, TR, TO, 0, true>), g, dim3(kBlock), 0, c->stream, a);
+        else hipLaunchKernelGGL((k_amg_post<FINE, TX, TR, TO>), g, dim3(kBlock), 0, c->stream, a);
+    }
 }
 
 // The finest level's sweep on a decomposed mesh, overlapped with the ghost update of its input (Ctx::overlap): the
@@ -1172,14 +1225,18 @@ static hipError_t launch_post_split(Ctx* c, const DevSell& A, const float* vals,
                                           SplitSell{c->d_slice_ghost, c->d_bslices, c->n_bslices}};
     hipError_t e;
     if ((e = hipEventRecord(c->ev_ready, c->stream)) != hipSuccess) return e;
-    launch_phase(c, SHK_PH_AMG_FINE, k_amg_post<true, float, double, float, 1>, dim3(std::min((A.nslice + 3) / 4, 2048)),
-                 dim3(kBlock), 0, a);
+    if (A.pk) launch_phase(c, SHK_PH_AMG_FINE, k_amg_post<true, float, double, float, 1, true>, dim3(std::min((A.nslice + 3) / 4, 2048)),
+                           dim3(kBlock), 0, a);
+    else launch_phase(c, SHK_PH_AMG_FINE, k_amg_post<true, float, double, float, 1>, dim3(std::min((A.nslice + 3) / 4, 2048)),
+                      dim3(kBlock), 0, a);
     if ((e = halo_begin_f32(c, x)) != hipSuccess) return e;
     if ((e = halo_end(c)) != hipSuccess) return e;
     if (c->n_bslices > 0) {
         PhaseTimer t(c, SHK_PH_HALO);
-        hipLaunchKernelGGL((k_amg_post<true, float, double, float, 2>), dim3(std::min((c->n_bslices + 3) / 4, 2048)),
-                           dim3(kBlock), 0, c->stream, a);
+        if (A.pk) hipLaunchKernelGGL((k_amg_post<true, float, double, float, 2, true>), dim3(std::min((c->n_bslices + 3) / 4, 2048)),
+                                     dim3(kBlock), 0, c->stream, a);
+        else hipLaunchKernelGGL((k_amg_post<true, float, double, float, 2>), dim3(std::min((c->n_bslices + 3) / 4, 2048)),
+                                dim3(kBlock), 0, c->stream, a);
     }
     return hipSuccess;
 }
@@ -1348,8 +1405,8 @@ static hipError_t amg_vcycle_t(Ctx* c, AmgHierarchy& H, const TR* rin, float* zo
         const DevSell A = level_sell(c, H, l);
         const dim3 g(std::min((A.nslice + 3) / 4, 2048));
         // byte accounting (shk_profile.bytes): the streams of this level's operator and of its A*P
-        const double a_bytes = l == 0 ? H.top_bytes : sell_bytes(H.lv[l].slots, H.lv[l].slots16, H.lv[l].nslice, 4);
-        const double ap_bytes = X.with_ap ? sell_bytes(X.ap_slots, X.ap_slots16, X.ap_nslice, 4) : 0.0;
+        const double a_bytes = l == 0 ? H.top_bytes : amg_sell_bytes(H.lv[l].slots, H.lv[l].slots16, H.lv[l].nslice, H.lv[l].pk != nullptr);
+        const double ap_bytes = X.with_ap ? amg_sell_bytes(X.ap_slots, X.ap_slots16, X.ap_nslice, X.ap_pk != nullptr) : 0.0;
         const double first_bytes = ap_bytes + (double)X.n_fine * (4 + (l == 0 ? sizeof(TR) : 4) + 4 + 4) + 4.0 * (double)X.n_coarse_cols;
         if (l == 0) {
             // level 0: right-hand side = the Krylov vector (double); the iterate and the result are float.
@@ -1366,13 +1423,16 @@ static hipError_t amg_vcycle_t(Ctx* c, AmgHierarchy& H, const TR* rin, float* zo
                     return hipSuccess;
             }
             if (fused) {
-                AmgFirstArgs<TR> f{DevSell{X.n_fine, X.n_coarse_cols, X.ap_nslice, sell_fits_cache(X.ap_slots, kAmgSlotBytes),
-                                           X.ap_ptr, X.ap_col, X.ap_rowlen, X.ap_cbase, X.ap_ptr16, X.ap_col16},
-                                   X.ap_vals, H.top_dinv, rin, e_cols, X.agg, agg_off, H.x0, omega, alpha, done,
+                AmgFirstArgs<TR> f{ap_sell(X), X.ap_vals, H.top_dinv, rin, e_cols, X.agg, agg_off, H.x0, omega, alpha, done,
                                    frozen ? X.ghost_col : nullptr, frozen ? X.n_ghost : 0, nullptr};
                 note_bytes(c, first_bytes);
-                if (frozen) launch_phase(c, ph(SHK_PH_AMG_FIRST), k_amg_first<true, TR, true>, g, dim3(kBlock), 0, f);
-                else launch_phase(c, ph(SHK_PH_AMG_FIRST), k_amg_first<true, TR>, g, dim3(kBlock), 0, f);
+                if (frozen) {
+                    if (f.AP.pk) launch_phase(c, ph(SHK_PH_AMG_FIRST), k_amg_first<true, TR, true, true>, g, dim3(kBlock), 0, f);
+                    else launch_phase(c, ph(SHK_PH_AMG_FIRST), k_amg_first<true, TR, true>, g, dim3(kBlock), 0, f);
+                } else {
+                    if (f.AP.pk) launch_phase(c, ph(SHK_PH_AMG_FIRST), k_amg_first<true, TR, false, true>, g, dim3(kBlock), 0, f);
+                    else launch_phase(c, ph(SHK_PH_AMG_FIRST), k_amg_first<true, TR>, g, dim3(kBlock), 0, f);
+                }
             } else {
                 {
                     PhaseTimer t(c, ph(SHK_PH_AMG_COARSE));
@@ -1414,14 +1474,17 @@ static hipError_t amg_vcycle_t(Ctx* c, AmgHierarchy& H, const TR* rin, float* zo
                     return hipSuccess;
             }
             if (fused) {
-                AmgFirstArgs<float> f{DevSell{X.n_fine, X.n_coarse_cols, X.ap_nslice, sell_fits_cache(X.ap_slots, kAmgSlotBytes),
-                                              X.ap_ptr, X.ap_col, X.ap_rowlen, X.ap_cbase, X.ap_ptr16, X.ap_col16},
-                                      X.ap_vals, L.dinv, L.r, e_cols, X.agg, agg_off, L.x, lw1, alpha, done,
+                AmgFirstArgs<float> f{ap_sell(X), X.ap_vals, L.dinv, L.r, e_cols, X.agg, agg_off, L.x, lw1, alpha, done,
                                       frozen ? X.ghost_col : nullptr, frozen ? X.n_ghost : 0, L.x2};
                 PhaseTimer t(c, ph_level(l));
                 note_bytes(c, first_bytes);
-                if (frozen) hipLaunchKernelGGL((k_amg_first<false, float, true>), g, dim3(kBlock), 0, c->stream, f);
-                else hipLaunchKernelGGL((k_amg_first<false, float>), g, dim3(kBlock), 0, c->stream, f);
+                if (frozen) {
+                    if (f.AP.pk) hipLaunchKernelGGL((k_amg_first<false, float, true, true>), g, dim3(kBlock), 0, c->stream, f);
+                    else hipLaunchKernelGGL((k_amg_first<false, float, true>), g, dim3(kBlock), 0, c->stream, f);
+                } else {
+                    if (f.AP.pk) hipLaunchKernelGGL((k_amg_first<false, float, false, true>), g, dim3(kBlock), 0, c->stream, f);
+                    else hipLaunchKernelGGL((k_amg_first<false, float>), g, dim3(kBlock), 0, c->stream, f);
+                }
             } else {
                 {
                     PhaseTimer t(c, ph_level(l));

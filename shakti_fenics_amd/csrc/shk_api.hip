@@ -255,6 +255,9 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
             if ((e = upload(c, &X.ap_gptr, LP.ap_gptr)) != hipSuccess) return e;
             if ((e = upload(c, &X.ap_glist, LP.ap_glist)) != hipSuccess) return e;
             if ((e = dev_alloc(c, &X.ap_vals, (size_t)X.ap_slots)) != hipSuccess) return e;
+            if (amg_packed_level(LP.AP.n_rows, X.ap_slots16)) {
+                if ((e = dev_alloc(c, &X.ap_pk, (size_t)X.ap_slots16)) != hipSuccess) return e;
+            }
         }
         if (!LP.ghost_col.empty()) {
             X.n_ghost = (int32_t)LP.ghost_col.size();
@@ -283,6 +286,9 @@ hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H,
             have_prev = true;
             const size_t nr = std::max<size_t>((size_t)L.nslice * kSlice, (size_t)L.n_cols);
             if ((e = dev_alloc(c, &L.vals, (size_t)L.slots)) != hipSuccess) return e;
+            if (amg_packed_level(L.n, L.slots16)) {
+                if ((e = dev_alloc(c, &L.pk, (size_t)L.slots16)) != hipSuccess) return e;
+            }
             float** vs[] = {&L.dinv, &L.x, &L.x2, &L.x3, &L.r};
             for (float** v : vs) {
                 if ((e = dev_alloc(c, v, nr)) != hipSuccess) return e;
@@ -448,6 +454,9 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
     if ((e = dev_alloc(c, &c->d_vals, (size_t)c->slots)) != hipSuccess) return bail(e, "alloc vals");
     if ((e = dev_alloc(c, &c->d_vals_s, (size_t)c->slots)) != hipSuccess) return bail(e, "alloc vals_s");
     if ((e = dev_alloc(c, &c->d_vals32, (size_t)c->slots)) != hipSuccess) return bail(e, "alloc vals32");
+    if (amg_packed_level(c->n_own, c->slots16)) {
+        if ((e = dev_alloc(c, &c->d_pk, (size_t)c->slots16)) != hipSuccess) return bail(e, "alloc packed values");
+    }
     if ((e = dev_alloc(c, &c->d_dinv32, nl)) != hipSuccess) return bail(e, "alloc dinv32");
     if ((e = zero_async(c, c->d_dinv32, nl * sizeof(float))) != hipSuccess) return bail(e, "memset");
     if ((e = dev_alloc(c, &c->d_bcflag, nl)) != hipSuccess) return bail(e, "alloc bcflag");

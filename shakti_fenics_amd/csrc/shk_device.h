@@ -69,6 +69,17 @@ struct DevSell {
     const int32_t* cbase;    // per slice: base column of the 16-bit offsets, or -1
     const int32_t* ptr16;
     const uint16_t* col16;
+    // Packed smoother copy (multigrid levels of >= SHK_AMG_BF16_ROWS rows; nullptr otherwise): one 32-bit word per slot of
+    // the slices with 16-bit columns, (bfloat16 value << 16) | column offset, indexed like col16.  ONE load per slot instead
+    // of a 4-byte and a 2-byte one, 4 B instead of 6.  Only smoothing sweeps read it: the Galerkin products, 1/diag and the
+    // spectral estimates keep the float values (slices with 32-bit columns too).
+    // The rounded entries are applied to DIFFERENCES:  (A x)_i = rs_i x_i + sum_{j != i} a~_ij (x_j - x_i),  rs_i = sum_j a_ij
+    // summed in float.  Rounding then costs 2^-9 of the LOCAL VARIATION of x and nothing on its smooth part -- which is
+    // what the operator annihilates (rs_i << a_ii) and what plain rounding was measured to spoil: applied to x_j itself,
+    // the row sums move by ~2^-9 a_ii and the Krylov iterations of the 10M-row mesh rise from 555 to 664 (with the
+    // differences: 554).  The row's own slot -- the diagonal; for A*P the column of the row's own aggregate -- multiplies
+    // x_i - x_i = 0 in that form, so it is the slot that carries rs_i (as bfloat16: 2^-9 of a small number).
+    const uint32_t* pk = nullptr;
 };
 
 // One SELL-64 slice times x: the lane's row sum.  Four streams: 16- or 32-bit columns, and non-temporal
@@ -120,6 +131,41 @@ __device__ __forceinline__ auto sell_width(const TV* __restrict__ vp, const TC* 
         default: return sum;
     }
 }
+// The same for the packed smoother copy (DevSell::pk).
+// own: the row's own column as a 16-bit offset; xi = x[own column]
+template <bool NT, int W, class TX>
+__device__ __forceinline__ float sell_fixed_pk(const uint32_t* __restrict__ pp, const TX* __restrict__ xb, uint32_t own, float xi) {
+    uint32_t w[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) w[k] = sell_ld<NT>(pp + k * kSlice);
+    float sum = 0;
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        const uint32_t c = w[k] & 0xffffu;
+        const float d = (float)xb[c] - xi;
+        sum += __uint_as_float(w[k] & 0xffff0000u) * (c == own ? xi : d);
+    }
+    return sum;
+}
+template <bool NT, int WMAX, class TX>
+__device__ __forceinline__ float sell_width_pk(const uint32_t* __restrict__ pp, const TX* __restrict__ xb, int width, uint32_t own, float xi) {
+    float sum = 0;
+    while (width > WMAX) {
+        sum += sell_fixed_pk<NT, WMAX>(pp, xb, own, xi);
+        pp += WMAX * kSlice; width -= WMAX;
+    }
+    switch (width) {
+        case 1: return sum + sell_fixed_pk<NT, 1>(pp, xb, own, xi);
+        case 2: return sum + sell_fixed_pk<NT, 2>(pp, xb, own, xi);
+        case 3: return sum + sell_fixed_pk<NT, 3>(pp, xb, own, xi);
+        case 4: return sum + sell_fixed_pk<NT, 4>(pp, xb, own, xi);
+        case 5: return sum + sell_fixed_pk<NT, 5>(pp, xb, own, xi);
+        case 6: return sum + sell_fixed_pk<NT, 6>(pp, xb, own, xi);
+        case 7: return sum + sell_fixed_pk<NT, 7>(pp, xb, own, xi);
+        case 8: return sum + sell_fixed_pk<NT, 8>(pp, xb, own, xi);
+        default: return sum;
+    }
+}
 // XCD-aware work distribution for streaming kernels (MI355X: 8 XCDs with private 4 MiB L2s, workgroups are
 // dealt round-robin, so blockIdx % 8 labels the XCD).  Each XCD gets one contiguous eighth of the slice groups
 // and its workgroups sweep it side by side, so the x-vector lines shared by neighbouring rows are fetched into
@@ -160,6 +206,22 @@ template <int WMAX = 8, class TV, class TX>
 __device__ __forceinline__ auto sell_row_sum(const DevSell& A, const SellMeta& m, const TV* __restrict__ vals,
                                              const TX* __restrict__ x, int lane) -> decltype(TV() * TX()) {
     return A.xcd_local ? sell_row_sum_t<false, WMAX>(A, m, vals, x, lane) : sell_row_sum_t<true, WMAX>(A, m, vals, x, lane);
+}
+// PK: slices with 16-bit columns come from the packed copy (A.pk must be set), the others from vals / col as before
+// (own_col: the row's own column -- the row itself for a square operator, its own aggregate for A*P; xi = x[own_col])
+template <bool PK, class TX>
+__device__ __forceinline__ float sell_row_sum_pk(const DevSell& A, const SellMeta& m, const float* __restrict__ vals,
+                                                 const TX* __restrict__ x, int lane, int own_col, float xi) {
+    if constexpr (!PK) return sell_row_sum(A, m, vals, x, lane);
+    else {
+        if (m.cb >= 0) {
+            const uint32_t* __restrict__ pp = A.pk + m.p16 + lane;
+            const uint32_t own = (uint32_t)(own_col - m.cb);
+            return A.xcd_local ? sell_width_pk<false, 8>(pp, x + m.cb, m.width, own, xi)
+                               : sell_width_pk<true, 8>(pp, x + m.cb, m.width, own, xi);
+        }
+        return sell_row_sum(A, m, vals, x, lane);
+    }
 }
 template <int WMAX = 8, class TV, class TX>
 __device__ __forceinline__ auto sell_row_sum(const DevSell& A, const TV* __restrict__ vals,
@@ -306,6 +368,12 @@ inline int32_t sell_fits_cache(int64_t slots, int bytes_per_slot = 12) {   // 8 
     return slots * bytes_per_slot < (int64_t)192 << 20 ? 1 : 0;
 }
 constexpr int kAmgSlotBytes = 8;   // float value + (mostly 16-bit) column
+constexpr int kAmgPackedSlotBytes = 4;   // DevSell::pk
+// rows from which a multigrid level's sweeps stream the packed bfloat16 copy (SHK_AMG_BF16_ROWS; 0: never)
+inline bool amg_packed_level(int64_t n_rows, int64_t slots16) {
+    const int64_t t = tunables().amg_bf16_rows;
+    return t > 0 && n_rows >= t && slots16 > 0;
+}
 
 // Multigrid hierarchy on the device (shk_amg.hip).  Level 0 is the Jacobian itself (Ctx::d_vals, d_dinv).
 struct AmgLevel {
@@ -315,6 +383,7 @@ struct AmgLevel {
     uint16_t* col16 = nullptr;
     uint8_t* rowlen = nullptr;
     float *vals = nullptr, *dinv = nullptr, *x = nullptr, *x2 = nullptr, *x3 = nullptr, *r = nullptr;   // preconditioner precision
+    uint32_t* pk = nullptr;           // packed smoother copy (DevSell::pk), large levels only
 };
 struct AmgXfer {  // level l -> l+1
     int32_t n_fine = 0, n_coarse = 0, n_coarse_cols = 0;
@@ -332,6 +401,7 @@ struct AmgXfer {  // level l -> l+1
     uint16_t* ap_col16 = nullptr;
     uint8_t* ap_rowlen = nullptr;
     float* ap_vals = nullptr;
+    uint32_t* ap_pk = nullptr;        // packed smoother copy of A*P (DevSell::pk)
     // decomposed levels: coarse column of each ghost column of the fine level (frozen-ghost smoothing, AmgHierarchy)
     int32_t* ghost_col = nullptr;
     int32_t n_ghost = 0;
@@ -499,6 +569,7 @@ struct Ctx {
     size_t asm_lds_res = 0, asm_region_a_res = 0;   // the residual-only instance: 3 instead of 12 staged tensor entries per cell
     double *d_F = nullptr, *d_vals = nullptr, *d_vals_s = nullptr, *d_dinv = nullptr;
     float *d_vals32 = nullptr, *d_dinv32 = nullptr;   // float copies read by the multigrid preconditioner
+    uint32_t* d_pk = nullptr;                         // ... and the packed copy its level-0 sweeps stream (DevSell::pk)
     // Krylov vectors
     double *d_r = nullptr, *d_rhat = nullptr, *d_p = nullptr, *d_v = nullptr, *d_s = nullptr, *d_t = nullptr,
            *d_y = nullptr, *d_ytot = nullptr, *d_rhs = nullptr;
@@ -554,9 +625,10 @@ struct Ctx {
         return DevSell{(int32_t)n_own, (int32_t)n_loc, plan.A.nslice, sell_fits_cache(slots), d_sell_ptr, d_sell_col,
                        d_rowlen, d_cbase, d_ptr16, d_col16};
     }
-    DevSell sell32() const {   // same pattern, cache rule of the float copy
+    DevSell sell32() const {   // same pattern, cache rule of the float copy (of the packed one where it exists)
         DevSell A = sell();
-        A.xcd_local = sell_fits_cache(slots, kAmgSlotBytes);
+        A.xcd_local = sell_fits_cache(slots, d_pk ? kAmgPackedSlotBytes : kAmgSlotBytes);
+        A.pk = d_pk;
         return A;
     }
 };
@@ -639,6 +711,11 @@ hipError_t allreduce_part_arrays(Ctx* c, const double* part, double* red, int ns
 // Byte accounting of the profiled launches (shk_profile.bytes): a launch site notes what its kernel has to move BEFORE
 // it launches (launch_phase) or inside the PhaseTimer scope that times it.
 inline void note_bytes(Ctx* c, double bytes) { if (c->profiling) c->pending_bytes += bytes; }
+// bytes one sweep over a multigrid operator streams: packed slices 4 B per slot, the others float value + column
+inline double amg_sell_bytes(int64_t slots, int64_t slots16, int64_t nslice, bool packed) {
+    if (!packed) return (double)slots * 4 + 2.0 * (double)slots16 + 4.0 * (double)(slots - slots16) + 16.0 * (double)nslice;
+    return 4.0 * (double)slots16 + 8.0 * (double)(slots - slots16) + 16.0 * (double)nslice;
+}
 inline double sell_bytes(int64_t slots, int64_t slots16, int64_t nslice, int value_bytes) {
     return (double)slots * value_bytes + 2.0 * (double)slots16 + 4.0 * (double)(slots - slots16) + 16.0 * (double)nslice;
 }

@@ -35,6 +35,8 @@ struct Tunables {
     bool fused_restrict = true;   // SHK_FUSED_RESTRICT  0: one launch per restriction
     bool amg_fused_sweeps = true; // SHK_AMG_FUSED_SWEEPS  0: one launch per smoothing sweep on the small levels
     int64_t amg_fused_rows = 320000;   // SHK_AMG_FUSED_ROWS  largest level (rows) whose four sweeps run in one launch
+    int64_t amg_bf16_rows = 500000;    // SHK_AMG_BF16_ROWS  levels of at least that many rows smooth on the packed bfloat16 copy
+                                       //                  of their operator (DevSell::pk); 0: float values everywhere
     double amg_w1 = 0.0, amg_w2 = 0.0;   // SHK_AMG_W1 / W2  absolute dampings of the two finest-level sweeps
     int amg_halo_levels = -1;     // SHK_AMG_HALO_LEVELS  decomposed levels whose sweeps see their neighbours (-1 = all)
     int64_t amg_rep_rows = -1;    // SHK_AMG_REP_ROWS global size from which the coarse levels are replicated (-1 = default)
@@ -91,6 +93,7 @@ inline bool tunable_apply(Tunables& t, const std::string& name, const char* s) {
     if (name == "SHK_FUSED_RESTRICT") return B(t.fused_restrict);
     if (name == "SHK_AMG_FUSED_SWEEPS") return B(t.amg_fused_sweeps);
     if (name == "SHK_AMG_FUSED_ROWS") return L(t.amg_fused_rows);
+    if (name == "SHK_AMG_BF16_ROWS") return L(t.amg_bf16_rows);
     if (name == "SHK_AMG_W1") return D(t.amg_w1);
     if (name == "SHK_AMG_W2") return D(t.amg_w2);
     if (name == "SHK_AMG_HALO_LEVELS") return I(t.amg_halo_levels);
@@ -122,7 +125,7 @@ inline const char* const* tunable_names(int* n) {
         "SHK_ASM_SLICES", "SHK_ASM_CELLS", "SHK_SORT_WINDOW", "SHK_REORDER", "SHK_XCD", "SHK_AMG", "SHK_AMG_COARSEST",
         "SHK_AMG_ALPHA", "SHK_AMG_COARSE4", "SHK_AMG_COARSE4_FROM", "SHK_AMG_DENSE_PERIOD", "SHK_AMG_W_ROWS",
         "SHK_AMG_DAMP_SCALE", "SHK_AMG_LANCZOS", "SHK_AMG_REUSE", "SHK_AMG_LAMBDA_PERIOD", "SHK_FUSED_RESTRICT",
-        "SHK_AMG_FUSED_SWEEPS", "SHK_AMG_FUSED_ROWS", "SHK_AMG_W1", "SHK_AMG_W2", "SHK_AMG_HALO_LEVELS", "SHK_AMG_REP_ROWS",
+        "SHK_AMG_FUSED_SWEEPS", "SHK_AMG_FUSED_ROWS", "SHK_AMG_BF16_ROWS", "SHK_AMG_W1", "SHK_AMG_W2", "SHK_AMG_HALO_LEVELS", "SHK_AMG_REP_ROWS",
         "SHK_AMG_GHOST_EXCHANGE", "SHK_AMG_E_EXCHANGE", "SHK_GAL_ILP0", "SHK_GAL_ILP1", "SHK_GAL_GRID0", "SHK_GAL_GRID1", "SHK_GAL_CONTIG0",
         "SHK_GAL_CONTIG1", "SHK_GJ_PIVOTWISE", "SHK_WARM_ITS", "SHK_KRYLOV_CHUNK", "SHK_KRYLOV_NEAR", "SHK_PREDICT_LAST",
         "SHK_COMM_TIMEOUT_S", "SHK_OVERLAP", "SHK_DEBUG", "SHK_ASM_ABLATE"};

@@ -415,6 +415,41 @@ def test_fused_four_sweep_smoother_is_the_same_preconditioner(hip):
     assert out["1"][2] < 0.5 * out["0"][2], (out["1"][2], out["0"][2])     # far fewer launches on the small levels
 
 
+def test_packed_bfloat16_smoother_copy_keeps_solution_and_iteration_counts(hip):
+    """Levels of >= SHK_AMG_BF16_ROWS rows smooth on a packed copy of their operator (bfloat16 value + 16-bit column in one
+    word, applied to differences x_j - x_i with the float row sum in the row's own slot: DevSell::pk).  Against float
+    values everywhere (SHK_AMG_BF16_ROWS=0) on a 250k-DOF mesh with EVERY sparse level packed (threshold 1): the solution of
+    the linear system agrees to the Krylov tolerance and the iteration counts to 10 % -- rounding the entries the plain way
+    (applied to x_j) costs +20 % at 10M rows, which is what this test would catch.  (Slices whose columns span more than
+    65535 rows -- those along the first cuts of the k-d ordering -- keep float values and 32-bit columns inside the same
+    kernels.)"""
+    from shakti_fenics_amd.mesh import rectangle_mesh
+    from shakti_fenics_amd.synthetic import N_BDRY, outflow_predicate, synthetic_fields
+    dom = rectangle_mesh(1118, 224, 100e3, 20e3, order="morton")
+    sf = synthetic_fields(dom, storage_on=True, moulins=4)
+    nv = dom.num_vertices
+    f = O.Fields(N=sf["N_init"].copy(), N_n=sf["N_init"].copy(), b=np.abs(sf["b_init"]), q=sf["q_init"].copy(),
+                 melt_n=np.zeros(nv), z_b=sf["z_b"], z_s=sf["z_s"], G=sf["G"], storage=sf["lake_bdry"], inputs=sf["inputs"])
+    bc = O.boundary_dofs(dom.xy, dom.cells, outflow_predicate(dom))
+    out = {}
+    for rows in ("0", "1"):
+        with hip.tunables(SHK_AMG_BF16_ROWS=rows):
+            ctx = hip.ShaktiHip(dom.xy, dom.cells)
+        ctx.set_params(precond=hip.PRECOND["amg"])
+        upload(ctx, f, bc, N_BDRY)
+        its = []
+        for dt in (360.0, 3600.0):
+            ctx.assemble(dt)
+            n, conv, rr = ctx.linear_solve()
+            assert conv
+            its.append(n)
+        out[rows] = (its, ctx.get_field("dx"))
+        ctx.close()
+    assert rel_l2(out["0"][1], out["1"][1]) < 1e-6
+    for a, b in zip(out["0"][0], out["1"][0]):
+        assert abs(a - b) <= max(3, 0.1 * a), (out["0"][0], out["1"][0])
+
+
 @pytest.mark.parametrize("with_bc", [False, True])
 def test_residual_only_assembly_equals_the_full_pass(hip, with_bc):
     """The residual-only kernel instance (launched for the pass after the update expected to be a Newton solve's last)
