@@ -66,14 +66,22 @@ def test_interior_boundary_overlap_changes_nothing_but_the_schedule():
     assert all(abs(x[1] - y[1]) <= max(4, 0.25 * y[1]) for x, y in zip(on["infos"], off["infos"])), (on["infos"], off["infos"])
 
 
-@pytest.mark.parametrize("rep_rows,overlap", [("30000", "0"), ("8000", "0"), ("30000", "1")])
-def test_replicated_coarse_levels_four_subdomains(rep_rows, overlap):
+@pytest.mark.parametrize("rep_rows,overlap,bf16_rows", [("30000", "0", None), ("8000", "0", None), ("30000", "1", None),
+                                                        ("8000", "0", "1"), ("30000", "1", "1")])
+def test_replicated_coarse_levels_four_subdomains(rep_rows, overlap, bf16_rows):
     """The gathered-and-replicated coarse part of the distributed multigrid on an 80k-DOF mesh
     split four ways, taking over at level 1 (20k global rows) and at level 2 (5k): same fields as the undecomposed run,
     same Newton counts, Krylov counts at the one-subdomain level.  (Four subdomains make the replicated level larger
-    than a subdomain's own share of it, the case that needs the reduction partials cleared.)"""
-    r = _launch(4, "gloo", 29565 + int(rep_rows) // 8000 + 10 * int(overlap), ("--precond", "amg", "--nx", "400", "--ny", "200"),
-                {"SHK_AMG_REP_ROWS": rep_rows, "SHK_OVERLAP": overlap})
+    than a subdomain's own share of it, the case that needs the reduction partials cleared.)
+    bf16_rows = "1": every sparse level of the decomposed part AND of the replicated part smooths on its packed bfloat16
+    copy (DevSell::pk; by default only levels of >= 500k rows per subdomain do): the frozen-ghost first sweep, the
+    interior / boundary passes and the transfer onto the global level (whose rows' own slot is a GLOBAL column) in their
+    packed instances."""
+    env = {"SHK_AMG_REP_ROWS": rep_rows, "SHK_OVERLAP": overlap}
+    if bf16_rows:
+        env["SHK_AMG_BF16_ROWS"] = bf16_rows
+    r = _launch(4, "gloo", 29565 + int(rep_rows) // 8000 + 10 * int(overlap) + (20 if bf16_rows else 0),
+                ("--precond", "amg", "--nx", "400", "--ny", "200"), env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     rep = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert rep["ok"] and rep["ghost_mismatch"] == 0.0 and max(rep["errs"].values()) < 1e-7
