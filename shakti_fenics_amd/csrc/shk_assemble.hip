@@ -257,6 +257,12 @@ __global__ __launch_bounds__(T, (JAC || NQ == 0) ? SHK_ASM_WAVES : SHK_ASM_WAVES
 
     const int blk = xcd_block(blockIdx.x, gridDim.x);
     const int tid = threadIdx.x;
+    // A block has ~584 cells and ~2100 slots: the last trip of the cell loop (and of the slot loop) occupies only the first
+    // one or two waves, i.e. always the SAME two SIMDs -- of both workgroups of a CU, whose waves are dealt to the SIMDs in
+    // the same order.  Every other generation of workgroups (blockIdx / 256: the two residents of a CU come from adjacent
+    // generations) therefore starts its loops two waves further on, so that the long and the short waves of the two
+    // residents share SIMDs.  Which thread computes which cell / slot changes; no result does.
+    const int rtid = (tid + (((blockIdx.x >> 8) & 1) << 7)) & (T - 1);
     // one descriptor (scalar loads) names everything this workgroup fetches: all its other loads depend on nothing else
     const int32_t* __restrict__ dsc = a.blk_desc + (size_t)kBlkDesc * blk;
     const int s0 = dsc[0], ns = dsc[1], c0 = dsc[2], ncell = dsc[3], h0 = dsc[4], nhalo = dsc[5];
@@ -271,7 +277,7 @@ __global__ __launch_bounds__(T, (JAC || NQ == 0) ? SHK_ASM_WAVES : SHK_ASM_WAVES
     ushort4 cvw[R];
 #pragma unroll
     for (int r = 0; r < R; ++r)
-        cvw[r] = (!SHK_ABLATE(8) && tid + r * T < ncell) ? cellv[tid + r * T] : make_ushort4(0, 0, 0, 0);
+        cvw[r] = (!SHK_ABLATE(8) && rtid + r * T < ncell) ? cellv[rtid + r * T] : make_ushort4(0, 0, 0, 0);
     for (int i = tid; i <= ns; i += T) sp[i] = a.A.ptr[s0 + i];
     for (int i = tid; i <= nrows; i += T) ip[i] = a.incptr[r0 + i];
     for (int i = tid; i < ninc; i += T) ic[i] = a.inccode[ip0 + i];
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(T, (JAC || NQ == 0) ? SHK_ASM_WAVES : SHK_ASM_WAVES
     CellOut out[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int t = tid + r * T;
+        const int t = rtid + r * T;
         if (t < ncell) {
             const ushort4 cv = SHK_ABLATE(8) ? cellv[t] : cvw[r];
             if (SHK_ABLATE(1)) {
@@ -339,14 +345,14 @@ __global__ __launch_bounds__(T, (JAC || NQ == 0) ? SHK_ASM_WAVES : SHK_ASM_WAVES
     if constexpr (JAC) {
 #pragma unroll
         for (int r = 0; r < kSlotIt; ++r) {
-            const int s = n0 + tid + r * T;
+            const int s = n0 + rtid + r * T;
             srcw[r] = s < n1 ? a.slotsrc[s] : kSrcEmpty;
         }
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int t = tid + r * T;
+        const int t = rtid + r * T;
         if (t < ncell) {
             if constexpr (JAC) {
 #pragma unroll
@@ -379,7 +385,7 @@ __global__ __launch_bounds__(T, (JAC || NQ == 0) ? SHK_ASM_WAVES : SHK_ASM_WAVES
         const int sp1 = ns > 1 ? sp[1] : 0x7FFFFFFF, sp2 = ns > 2 ? sp[2] : 0x7FFFFFFF, sp3 = ns > 3 ? sp[3] : 0x7FFFFFFF;
 #pragma unroll
         for (int r = 0; r < kSlotIt; ++r) {
-            const int s = n0 + tid + r * T;
+            const int s = n0 + rtid + r * T;
             if (s >= n1) break;
             const int j = (s >= sp1) + (s >= sp2) + (s >= sp3);
             const int off = s - (j == 0 ? n0 : j == 1 ? sp1 : j == 2 ? sp2 : sp3);

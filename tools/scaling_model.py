@@ -306,6 +306,10 @@ def report(res, a):
           f"* {rounds:.1f} message rounds: **{rounds * 0.010:.3f} / {rounds * 0.020:.3f} / {rounds * 0.030:.3f}** at 10 / 20 / 30 us each "
           "(measured floor of a grouped send + recv round on one GPU, no link crossed: 4.8 us + its pack kernel -- "
           "`profiles/r03_rccl_round_floor.txt`).",
+          f"* Not in the table: an all-gather is a RING of P - 1 hops, not one hop.  The {last['allgathers']:.1f} all-gathers of an iteration "
+          f"bring {last['bytes_allgathered'] / 1e3:.0f} KB to every GPU ({last['bytes_allgathered'] / 1e3 / max(last['allgathers'], 1e-9):.0f} KB each: the replicated level's "
+          f"right-hand side); at ~100 GB/s into a GPU that is {last['bytes_allgathered'] / 100e9 * 1e3:.3f} ms per iteration of bandwidth, and each "
+          "is likelier to cost 2-3 of the table's rounds than one.  `SHK_AMG_REP_ROWS` trades its size against one more exchanging level.",
           f"* A 6x step would need {one['kernel_ms'] / 6:.3f} ms per iteration: less than the shrinking work plus the replicated levels "
           f"({shrink + last['amg_rep']:.3f}) before a single message is sent."]
     return L
