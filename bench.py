@@ -61,7 +61,10 @@ def parse():
     ap.add_argument("--allow-host-staged", action="store_true",
                     help="if RCCL cannot be used, run the same solver over the host-staged gloo transport instead of failing")
     ap.add_argument("--strict-steps", type=int, default=2,
-                    help="extra steps (after the timed region) with krylov_newton_eta = 0 and krylov_warm_start = 0: round 1's rule")
+                    help="extra steps (after the timed region) with krylov_newton_eta = 0, krylov_warm_start = 0, krylov_forcing = 0: round 1's rule")
+    ap.add_argument("--forcing", type=float, default=0.1,
+                    help="shk_params.krylov_forcing (inexact Newton: non-final iterations stop at forcing x the residual the "
+                         "iteration is expected to leave behind; 0: every linear solve to the Newton-aware floor, as in round 2)")
     ap.add_argument("--warm-start", type=int, default=4, help="shk_params.krylov_warm_start (0: every linear solve starts from zero)")
     ap.add_argument("--steady-max", type=int, default=50, help="N=1: total steps of the steady-state march after the timed "
                     "region (0: skip); stops early once ||dN||/||N|| < 1e-8")
@@ -190,7 +193,7 @@ def main():
         run = make_runner(args, rank, world, local_rank)
     except _lib.ShaktiCommStall as exc:
         _lib.exit_on_stall(exc)
-    run.ctx.set_params(krylov_warm_start=args.warm_start)
+    run.ctx.set_params(krylov_warm_start=args.warm_start, krylov_forcing=args.forcing)
     say(f"setup done: {run.describe()}")
     switches = _lib.env_overrides()
     if switches:
@@ -265,9 +268,13 @@ def main():
             "newton_its": newton, "krylov_its": krylov,
             "krylov_its_per_newton": krylov / max(newton, 1),
             "krylov_warm_start": run.ctx.get_params().krylov_warm_start, "krylov_newton_eta": run.ctx.get_params().krylov_newton_eta,
+            "krylov_forcing": run.ctx.get_params().krylov_forcing,
             "krylov": f"BiCGStab, right preconditioner {args.precond}; every linear solve runs until its TRUE residual is below "
                       f"max({args.krylov_rtol:g} ||F_k||, 0.1 x Newton's own stopping threshold max(1e-10, 1e-9 ||F_0||)) "
                       "(shk_params.krylov_newton_eta); "
+                      + (f"a Newton iteration that the previous step's history says cannot be the last stops its linear solve at "
+                         f"{args.forcing:g} x the residual it is expected to leave behind (shk_params.krylov_forcing: inexact Newton; "
+                         "the iteration expected to end the solve is solved as before); " if args.forcing > 0 else "")
                       + (f"the solve of Newton iteration k starts from the least-squares combination of the solutions of iteration k "
                          f"of the previous {args.warm_start} steps (shk_params.krylov_warm_start) " if args.warm_start > 0
                          else "every solve starts from zero ")
@@ -324,7 +331,7 @@ def main():
         # the same workload continued with every linear solve started from zero and driven to krylov_rtol ||F_k||
         # (krylov_newton_eta = 0, krylov_warm_start = 0): what the Newton-aware stopping floor and the warm start save,
         # reported beside the headline, never instead of it
-        run.ctx.set_params(krylov_newton_eta=0.0, krylov_warm_start=0)
+        run.ctx.set_params(krylov_newton_eta=0.0, krylov_warm_start=0, krylov_forcing=0.0)
         barrier()
         t1 = time.perf_counter()
         nn = kk = 0
@@ -334,11 +341,11 @@ def main():
             kk += info.krylov_its
         barrier()
         w = time.perf_counter() - t1
-        run.ctx.set_params(krylov_newton_eta=0.1, krylov_warm_start=args.warm_start)
+        run.ctx.set_params(krylov_newton_eta=0.1, krylov_warm_start=args.warm_start, krylov_forcing=args.forcing)
         out["strict_linear_solves"] = {"value": nv * nn / w if nn else 0.0, "unit": "DOF-updates/s", "steps": args.strict_steps,
                                        "ms_per_step": 1e3 * w / args.strict_steps, "newton_its": nn, "krylov_its": kk,
                                        "krylov_its_per_newton": kk / max(nn, 1),
-                                       "note": "krylov_newton_eta = 0, krylov_warm_start = 0: every linear solve from zero to 1e-10 ||F_k||, as in round 1"}
+                                       "note": "krylov_newton_eta = 0, krylov_warm_start = 0, krylov_forcing = 0: every linear solve from zero to 1e-10 ||F_k||, as in round 1"}
         say(f"strict leg done: {nn} newton, {kk} krylov, {w:.2f} s")
     if not args.no_roofline:
         roof = run.roofline(HBM_PEAK_GBS)  # one more (collective) step with per-launch hipEvents

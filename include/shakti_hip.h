@@ -43,6 +43,14 @@ typedef struct shk_params {
                                    eta * max(newton_atol, newton_rtol ||F_0||): Newton's own stopping threshold, beyond
                                    which more digits cannot change its decision.  Default 0.1 (= krylov_rtol ||F_0|| for
                                    the first iteration); 0 = always solve to krylov_rtol ||F_k|| */
+    double krylov_forcing;      /* inexact Newton inside shk_newton_solve (round 3).  The previous solve recorded, per Newton
+                                   iteration k, the ratio ||F_{k+1}|| / ||F_k||; e_k = ratio_k ||F_k|| is therefore what iteration
+                                   k of THIS solve is expected to leave behind however well its linear system is solved (the
+                                   nonlinear remainder).  While e_k > 10 x Newton's stopping threshold -- another iteration
+                                   will follow anyway -- the linear solve stops at a true residual of krylov_forcing * e_k
+                                   instead of ten digits below ||F_k||: digits the next iteration recovers for free.  The
+                                   iteration expected to END the solve is solved as tightly as before, so the converged state
+                                   and (in every test) the Newton counts are those of exact solves.  Default 0.1; 0 = off */
     int32_t newton_max_it;
     int32_t krylov_max_it;
     int32_t krylov_check_every; /* iterations enqueued between host stop-flag polls; 0 = automatic */
@@ -251,8 +259,9 @@ int shk_time_kernel(shk_ctx* ctx, int32_t phase, int32_t reps, double dt, double
  * the last of a solve: no element Jacobians, no slot phase), `reps` times between two events. */
 int shk_time_assemble_residual(shk_ctx* ctx, int32_t reps, double dt, double* avg_ms);
 /* Assembly passes since creation: n[0] full (residual + Jacobian), n[1] residual-only (predicted last iteration of a
- * Newton solve), n[2] full passes repeated because the prediction was wrong, n[3] Newton iterations of the last solve. */
-int shk_solver_stats(shk_ctx* ctx, int64_t n[4]);
+ * Newton solve), n[2] full passes repeated because the prediction was wrong, n[3] Newton iterations of the last solve, n[4] linear solves
+ * stopped by the forcing rule (shk_params.krylov_forcing). */
+int shk_solver_stats(shk_ctx* ctx, int64_t n[5]);
 
 /* Plan statistics for DESIGN.md / bench: n[0]=owned rows n[1]=ne n[2]=nnz n[3]=assembly blocks
  * n[4]=cells computed per assembly incl. cells shared between blocks n[5]=SELL slots (padded nnz)

@@ -37,7 +37,8 @@ def exit_on_stall(exc: BaseException):
 class shk_params(C.Structure):
     _fields_ = [(n, C.c_double) for n in
                 ("g", "rho_i", "rho_w", "nu", "Lh", "omega", "n", "A", "b_min",
-                 "newton_rtol", "newton_atol", "newton_relax", "krylov_rtol", "krylov_atol", "krylov_fail_rtol", "krylov_newton_eta")] + \
+                 "newton_rtol", "newton_atol", "newton_relax", "krylov_rtol", "krylov_atol", "krylov_fail_rtol", "krylov_newton_eta",
+                 "krylov_forcing")] + \
                [(n, C.c_int32) for n in ("newton_max_it", "krylov_max_it", "krylov_check_every", "precond", "krylov_warm_start")]
 
 
@@ -466,9 +467,10 @@ class ShaktiHip:
         return ms.value
 
     def solver_stats(self) -> dict:
-        n = (C.c_int64 * 4)()
+        n = (C.c_int64 * 5)()
         self._check(self.lib.shk_solver_stats(self._h, n))
         return dict(assemblies_full=int(n[0]), assemblies_residual_only=int(n[1]), assemblies_redone=int(n[2]),
+                    linear_solves_forced=int(n[4]),
                     newton_its_last_solve=int(n[3]))
 
     def plan_stats(self) -> dict:

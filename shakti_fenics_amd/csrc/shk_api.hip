@@ -351,6 +351,7 @@ int shk_default_params(shk_params* p) {
     p->krylov_rtol = 1e-10; p->krylov_atol = 1e-50; p->krylov_max_it = 20000; p->krylov_check_every = 0;
     p->krylov_fail_rtol = 1e-6;
     p->krylov_newton_eta = 0.1;
+    p->krylov_forcing = 0.1;
     p->krylov_warm_start = 4;
     p->precond = SHK_PC_JACOBI;
     return 0;
@@ -529,6 +530,7 @@ int shk_set_params(shk_ctx* ctx, const shk_params* p) {
     if (p->newton_max_it < 0 || p->krylov_max_it < 1 || p->krylov_check_every < 0) return fail("bad iteration limits");
     if (!(p->krylov_fail_rtol >= 0)) return fail("krylov_fail_rtol must be >= 0");
     if (!(p->krylov_newton_eta >= 0 && p->krylov_newton_eta <= 1)) return fail("krylov_newton_eta must be in [0, 1]");
+    if (!(p->krylov_forcing >= 0 && p->krylov_forcing <= 1)) return fail("krylov_forcing must be in [0, 1]");
     if (p->krylov_warm_start < 0 || p->krylov_warm_start > Ctx::kWarmDepth) return fail("krylov_warm_start must be in 0..4");
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (p->precond != SHK_PC_JACOBI && p->precond != SHK_PC_AMG && p->precond != SHK_PC_AMG_LOCAL)
@@ -914,7 +916,21 @@ int shk_newton_solve(shk_ctx* ctx, double dt, shk_solve_info* info) {
         const double newton_target = std::max(c->params.newton_atol, c->params.newton_rtol * I.residual0);
         // (an iterate whose residual is already 1e-3 of the step's first one has barely moved: the multigrid keeps its coarse
         // operators, amg_numeric_setup's top_only)
-        if (krylov_solve(c, &k, &kc, &rr, it, c->params.krylov_newton_eta * newton_target, r, it > 0 && r < 1e-3 * I.residual0)) return -1;
+        // Inexact Newton (shk_params.krylov_forcing): e = what this iteration left behind in the previous solve, scaled to
+        // this one's ||F_k||.  While e is an order of magnitude above Newton's threshold another iteration follows whatever
+        // this linear solve achieves, and it inherits a right-hand side of ~e either way: solving below forcing * e buys
+        // nothing.  The iteration expected to end the solve (e within 10 x of the threshold, or no history) is untouched.
+        // The history only speaks for a solve that resembles the one it came from: same dt, ||F_0|| within a factor 2
+        // (a forcing that jumps between two steps -- tests: moulin input x 20, then off -- moves ||F_0|| by more).
+        double floor = c->params.krylov_newton_eta * newton_target;
+        const bool similar = c->newton_hist_dt == dt && I.residual0 < 2.0 * c->newton_hist_f0 && c->newton_hist_f0 < 2.0 * I.residual0;
+        const double ratio = (similar && it < Ctx::kNewtonHist) ? c->newton_ratio[it] : 0.0;
+        if (c->params.krylov_forcing > 0.0 && ratio > 0.0 && ratio * r > 10.0 * newton_target) {
+            const double f = c->params.krylov_forcing * std::min(ratio, 1e-2) * r;
+            if (f > floor && f > c->params.krylov_rtol * r) { floor = f; c->n_forced += 1; }
+        }
+        const double r_before = r;
+        if (krylov_solve(c, &k, &kc, &rr, it, floor, r, it > 0 && r < 1e-3 * I.residual0)) return -1;
         I.krylov_its += k;
         // a solve that stagnated between krylov_rtol and krylov_fail_rtol sits on its fp64 floor
         // eps || |J| |dx| || (Newton absorbs it); beyond that -- max_it, breakdown, divergence -- it has failed
@@ -930,6 +946,7 @@ int shk_newton_solve(shk_ctx* ctx, double dt, shk_solve_info* info) {
         if (residual_norm(c, &r)) return -1;
         I.residual = r;
         if (!std::isfinite(r)) break;
+        if (it - 1 < Ctx::kNewtonHist) c->newton_ratio[it - 1] = r_before > 0.0 ? r / r_before : 0.0;
         conv = (r < c->params.newton_atol) || (I.residual0 > 0 && r / I.residual0 < c->params.newton_rtol);
         if (guess_last && !conv && it < c->params.newton_max_it) {   // mispredicted: this iterate's Jacobian is needed
             launch_assemble(c, dt);
@@ -938,6 +955,9 @@ int shk_newton_solve(shk_ctx* ctx, double dt, shk_solve_info* info) {
         }
     }
     c->newton_prev = it;
+    for (int k = it; k < Ctx::kNewtonHist; ++k) c->newton_ratio[k] = 0.0;   // iterations this solve did not run: no history
+    c->newton_hist_f0 = I.residual0;
+    c->newton_hist_dt = dt;
     HIPCHK(hipGetLastError());
     I.newton_its = it;
     I.converged = conv ? 1 : 0;
@@ -1277,11 +1297,11 @@ int shk_time_assemble_residual(shk_ctx* ctx, int32_t reps, double dt, double* av
     return 0;
 }
 
-int shk_solver_stats(shk_ctx* ctx, int64_t n[4]) {
+int shk_solver_stats(shk_ctx* ctx, int64_t n[5]) {
     CHECK_CTX(ctx);
     if (!n) return fail("null output");
     const Ctx* c = reinterpret_cast<Ctx*>(ctx);
-    n[0] = c->n_asm_full; n[1] = c->n_asm_res; n[2] = c->n_asm_redo; n[3] = c->newton_prev;
+    n[0] = c->n_asm_full; n[1] = c->n_asm_res; n[2] = c->n_asm_redo; n[3] = c->newton_prev; n[4] = c->n_forced;
     return 0;
 }
 

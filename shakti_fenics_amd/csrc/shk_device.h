@@ -607,6 +607,10 @@ struct Ctx {
     bool assembled = false;   // d_F holds the residual of the current state
     bool jac_valid = false;   // ... and d_vals / d_dinv its Jacobian (false after a residual-only pass)
     int newton_prev = 0;      // Newton iterations of the previous shk_newton_solve (predicts the last iteration of this one)
+    static constexpr int kNewtonHist = 16;
+    double newton_ratio[kNewtonHist] = {};   // ||F_{k+1}|| / ||F_k|| of the previous shk_newton_solve (0: none): shk_params.krylov_forcing
+    double newton_hist_f0 = 0.0, newton_hist_dt = 0.0;   // ||F_0|| and dt of the solve that history belongs to
+    int64_t n_forced = 0;                    // linear solves stopped by the forcing rule (shk_solver_stats)
     int64_t n_asm_full = 0, n_asm_res = 0, n_asm_redo = 0;   // assembly passes: full, residual-only, full after a misprediction
     double assembled_dt = 0.0;
     bool poisoned = false;   // a host wait hit the RCCL deadline (or shk_comm_mark_stalled): the stream will never drain, so

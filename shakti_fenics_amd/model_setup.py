@@ -44,6 +44,7 @@ _BUILD_KNOBS = dict(
     device=None,                # GPU of this rank: set in __init__ from SHK_DEVICE / LOCAL_RANK (one process per GPU)
     krylov_rtol=1e-10, krylov_max_it=20000,
     krylov_newton_eta=0.1,      # linear solves also stop 10x below Newton's own threshold (0: always to krylov_rtol ||F_k||)
+    krylov_forcing=0.1,         # inexact Newton: non-final iterations stop at 0.1 x the residual they are expected to leave (0: off)
     krylov_warm_start=4,        # linear solves start from the least-squares combination of the last 4 steps' solutions (0: from zero)
     preconditioner="amg",       # "amg" (default) | "amg_local" | "jacobi" (north_star's solver)
     ingest="device",            # where interp_data / set_lake_bdry evaluate: "device" (HIP kernels, bit-identical to

@@ -41,6 +41,7 @@ def _configure(ctx, md):
                    b_min=float(md.b_min), krylov_rtol=float(getattr(md, "krylov_rtol", 1e-10)),
                    krylov_max_it=int(getattr(md, "krylov_max_it", 20000)),
                    krylov_newton_eta=float(getattr(md, "krylov_newton_eta", 0.1)),
+                   krylov_forcing=float(getattr(md, "krylov_forcing", 0.1)),
                    krylov_warm_start=int(getattr(md, "krylov_warm_start", 4)),
                    precond=_lib.PRECOND[getattr(md, "preconditioner", "amg")])  # collective when md.size > 1
 

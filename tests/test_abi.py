@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_struct_layouts_match_the_header(lib):
-    assert ctypes.sizeof(lib.shk_params) == 16 * 8 + 5 * 4 + 4   # 5 int32 + tail padding to 8
+    assert ctypes.sizeof(lib.shk_params) == 17 * 8 + 5 * 4 + 4   # 5 int32 + tail padding to 8
     assert ctypes.sizeof(lib.shk_solve_info) == 4 * 4 + 3 * 8
     assert ctypes.sizeof(lib.shk_profile) == 3 * 20 * 8   # ms, launches, bytes; SHK_PH_COUNT = 20
 
