@@ -71,15 +71,18 @@ def test_pde_solver_object_api(tmp_path):
 @pytest.mark.parametrize("warm", [0, 4])
 def test_restart_continues_bit_for_bit(tmp_path, warm):
     """resume from the saved frames (the reference has no restart path).  With every linear solve
-    started from zero (md.krylov_warm_start = 0) the continuation is bit-identical to the uninterrupted run; with the
-    default warm start a resumed run has no previous solutions to start from, takes different Krylov paths to the same
-    tolerance and agrees to 1e-8 with identical Newton counts."""
+    started from zero and to the same tolerance (md.krylov_warm_start = 0, md.krylov_forcing = 0: no solver state carried
+    from one solve to the next) the continuation is bit-identical to the uninterrupted run; with the defaults a resumed run
+    has no previous solutions or residual ratios to go by, takes different Krylov paths to the same final tolerance and
+    agrees to 1e-8 with identical Newton counts."""
     from shakti_fenics_amd.setups import setup_synthetic_cooke2 as S
 
     def fresh(root):
         md = S.initialize(SerialComm(), nx=31, ny=31, days=8.0 / 24.0, results_root=root)
         md.nt_check = 1
         md.krylov_warm_start = warm
+        if warm == 0:
+            md.krylov_forcing = 0.0   # the other solver state carried from solve to solve (inexact Newton's residual ratios)
         return md
 
     md = fresh(tmp_path / "full")
