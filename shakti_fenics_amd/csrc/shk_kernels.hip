@@ -287,6 +287,28 @@ __global__ __launch_bounds__(kBlock) void k_bicg_init(int64_t n, const double* _
     }
 }
 
+// The stop test of k_bicg_s, one kernel EARLIER (round 3; one context only -- across subdomains ||r||^2 is reduced together
+// with (rhat.v), i.e. after the product, and an extra all-reduce per iteration would cost more than it saves).  k_bicg_s
+// learns that iterate `it` has converged only after the multigrid cycle and the product that open iteration `it` have
+// run: every solve paid one cycle + one product (0.55 ms at 10M rows, two solves per step) for a vector nobody reads.
+// One workgroup reduces the same partials in the same order first; behind its flag the cycle's launches return at once.
+// It takes the same decision from the same numbers as k_bicg_s would, and writes the same state.
+__global__ __launch_bounds__(kBlock) void k_krylov_check(int it, int max_it, double rtol2, double atol2, int np, int rs,
+                                                         const double* red, KrylovState* __restrict__ st) {
+    __shared__ double sh4[4];
+    if (st->done) return;
+    const double rr = reduce_partials(red + P_RR * rs, np, sh4);
+    const double target2 = (it == 0) ? fmax(rtol2 * rr, atol2) : st->target2;
+    int stop = 0, conv = 0;
+    if (!(rr > target2)) { stop = 1; conv = (rr <= target2); }
+    else if (it >= max_it) stop = 1;
+    if (stop && threadIdx.x == 0) {
+        if (it == 0) { st->target2 = target2; st->rhs2 = rr; st->rho[0] = rr; }
+        st->rr_last = rr;
+        st->converged = conv; st->its = it; st->rnorm2 = rr; st->done = 1;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_bicg_s(int64_t n, int it, int max_it, double rtol2, double atol2,
                                                    int np, int rs, const double* red, double* part,
                                                    const double* __restrict__ r, const double* __restrict__ v,
@@ -614,6 +636,11 @@ hipError_t krylov_iteration(Ctx* c, int it) {
     // leaves M^-1 p, M^-1 s in float (the product and the solution update read them as such)
     const double* A = c->use_amg ? c->d_vals : c->d_vals_s;
     const bool amg = c->use_amg;
+    if (amg && (c->comm.kind == Comm::NONE || c->comm.nranks <= 1) && tunables().krylov_early_check) {
+        PhaseTimer t(c, SHK_PH_VECTOR);
+        hipLaunchKernelGGL(k_krylov_check, dim3(1), b, 0, c->stream, it, c->params.krylov_max_it, c->cur_rtol2, c->cur_atol2,
+                           c->np, c->red_stride, c->d_red, c->d_state);
+    }
     if (amg && (e = amg_vcycle(c, *c->amg, c->d_p, c->d_phat)) != hipSuccess) return e;
     if ((e = krylov_product<1>(c, A, amg ? (const void*)c->d_phat : (const void*)c->d_p, c->d_v, nullptr)) != hipSuccess) return e;
     if ((e = allreduce_parts(c, P_RR, 2)) != hipSuccess) return e;
