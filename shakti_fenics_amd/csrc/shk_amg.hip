@@ -1219,23 +1219,24 @@ static void launch_post(Ctx* c, const DevSell& A, const float* vals, const float
 
 // The finest level's sweep on a decomposed mesh, overlapped with the ghost update of its input (Ctx::overlap): the
 // slices without ghost columns are swept while the exchange travels on comm_stream, the others after it has arrived.
-static hipError_t launch_post_split(Ctx* c, const DevSell& A, const float* vals, const float* dinv, const double* r,
+template <class TR>
+static hipError_t launch_post_split(Ctx* c, const DevSell& A, const float* vals, const float* dinv, const TR* r,
                                     float* x, float* xo, float w, const int* done) {
-    AmgSmoothArgs<float, double, float> a{A, vals, dinv, r, x, xo, w, done,
+    AmgSmoothArgs<float, TR, float> a{A, vals, dinv, r, x, xo, w, done,
                                           SplitSell{c->d_slice_ghost, c->d_bslices, c->n_bslices}};
     hipError_t e;
     if ((e = hipEventRecord(c->ev_ready, c->stream)) != hipSuccess) return e;
-    if (A.pk) launch_phase(c, SHK_PH_AMG_FINE, k_amg_post<true, float, double, float, 1, true>, dim3(std::min((A.nslice + 3) / 4, 2048)),
+    if (A.pk) launch_phase(c, SHK_PH_AMG_FINE, k_amg_post<true, float, TR, float, 1, true>, dim3(std::min((A.nslice + 3) / 4, 2048)),
                            dim3(kBlock), 0, a);
-    else launch_phase(c, SHK_PH_AMG_FINE, k_amg_post<true, float, double, float, 1>, dim3(std::min((A.nslice + 3) / 4, 2048)),
+    else launch_phase(c, SHK_PH_AMG_FINE, k_amg_post<true, float, TR, float, 1>, dim3(std::min((A.nslice + 3) / 4, 2048)),
                       dim3(kBlock), 0, a);
     if ((e = halo_begin_f32(c, x)) != hipSuccess) return e;
     if ((e = halo_end(c)) != hipSuccess) return e;
     if (c->n_bslices > 0) {
         PhaseTimer t(c, SHK_PH_HALO);
-        if (A.pk) hipLaunchKernelGGL((k_amg_post<true, float, double, float, 2, true>), dim3(std::min((c->n_bslices + 3) / 4, 2048)),
+        if (A.pk) hipLaunchKernelGGL((k_amg_post<true, float, TR, float, 2, true>), dim3(std::min((c->n_bslices + 3) / 4, 2048)),
                                      dim3(kBlock), 0, c->stream, a);
-        else hipLaunchKernelGGL((k_amg_post<true, float, double, float, 2>), dim3(std::min((c->n_bslices + 3) / 4, 2048)),
+        else hipLaunchKernelGGL((k_amg_post<true, float, TR, float, 2>), dim3(std::min((c->n_bslices + 3) / 4, 2048)),
                                 dim3(kBlock), 0, c->stream, a);
     }
     return hipSuccess;
@@ -1442,11 +1443,9 @@ static hipError_t amg_vcycle_t(Ctx* c, AmgHierarchy& H, const TR* rin, float* zo
                 if (halo && (e = halo_exchange_plan_f32(c, *HP, zout)) != hipSuccess) return e;
                 launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)zout, H.x0, omega, done, ph(SHK_PH_AMG_FINE), a_bytes);
             }
-            if constexpr (sizeof(TR) == sizeof(double)) {
-                if (halo && !frozen && c->overlap && H.plan_of[0] == 0 && A.ptr == c->d_sell_ptr) {
-                    if ((e = launch_post_split(c, A, H.top_vals, H.top_dinv, rin, H.x0, zout, w2, done)) != hipSuccess) return e;
-                    split_done = true;
-                }
+            if (halo && !frozen && c->overlap && H.plan_of[0] == 0 && A.ptr == c->d_sell_ptr) {   // (a context's own level 0)
+                if ((e = launch_post_split<TR>(c, A, H.top_vals, H.top_dinv, rin, H.x0, zout, w2, done)) != hipSuccess) return e;
+                split_done = true;
             }
             if (!split_done) {
                 if (halo && !frozen && (e = halo_exchange_plan_f32(c, *HP, H.x0)) != hipSuccess) return e;
@@ -1551,6 +1550,10 @@ static hipError_t amg_vcycle_t(Ctx* c, AmgHierarchy& H, const TR* rin, float* zo
 }
 
 hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) { return amg_vcycle_t<double>(c, H, rin, zout); }
+// The Krylov loop hands the cycle the float copies its vector kernels write beside p and s (Ctx::d_p32, d_s32): the cycle
+// reads its right-hand side three times on the finest level (restriction, first sweep, second sweep) and rounds it to
+// float on the way in either way.
+hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const float* rin, float* zout) { return amg_vcycle_t<float>(c, H, rin, zout); }
 
 // ------------------------------------------------------------------ distributed setup (collective)
 // One integer per row of a level travels as a double through that level's halo plan.

@@ -586,6 +586,7 @@ struct Ctx {
     AmgHierarchy amg_local, amg_dist;
     AmgHierarchy* amg = nullptr;    // the active one when use_amg
     float *d_phat = nullptr, *d_shat = nullptr;   // M^-1 p, M^-1 s: float, like everything the cycle produces
+    float *d_p32 = nullptr, *d_s32 = nullptr;     // float copies of p, s written by the kernels that produce them: the cycle's input
     bool use_amg = false;
     double* d_part = nullptr;  // 8 arrays of kMaxParts: this subdomain's partial sums
     double* d_red = nullptr;   // what the consumers read: d_part itself (one context), or P_COUNT scalars = this
@@ -609,6 +610,7 @@ struct Ctx {
     int newton_prev = 0;      // Newton iterations of the previous shk_newton_solve (predicts the last iteration of this one)
     static constexpr int kNewtonHist = 16;
     double newton_ratio[kNewtonHist] = {};   // ||F_{k+1}|| / ||F_k|| of the previous shk_newton_solve (0: none): shk_params.krylov_forcing
+    double newton_fk[kNewtonHist] = {};      // ... and its ||F_k||
     double newton_hist_f0 = 0.0, newton_hist_dt = 0.0;   // ||F_0|| and dt of the solve that history belongs to
     int64_t n_forced = 0;                    // linear solves stopped by the forcing rule (shk_solver_stats)
     int64_t n_asm_full = 0, n_asm_res = 0, n_asm_redo = 0;   // assembly passes: full, residual-only, full after a misprediction
@@ -703,6 +705,7 @@ hipError_t allgather_blocks(Ctx* c, void* buf, const std::vector<int64_t>& off);
 int amg_setup_distributed(Ctx* c, std::string& err);  // collective
 hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense, bool decided = false, bool top_only = false);
 hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout);
+hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const float* rin, float* zout);
 // upload one host hierarchy (shk_api.hip: owns the allocation helpers)
 hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H, int64_t n_loc0,
                       const std::vector<int32_t>* krank0 = nullptr,    // krank0: k-d ranks of the top rows (default: the mesh's)

@@ -268,12 +268,14 @@ void launch_norm2(Ctx* c, const double* x, double* partials) {
 __global__ __launch_bounds__(kBlock) void k_bicg_init(int64_t n, const double* __restrict__ rhs,
                                                       double* __restrict__ r, double* __restrict__ rhat,
                                                       double* __restrict__ p, double* __restrict__ y,
-                                                      double* __restrict__ part, KrylovState* __restrict__ st) {
+                                                      double* __restrict__ part, KrylovState* __restrict__ st,
+                                                      float* __restrict__ p32) {   // p32: the multigrid cycle's input (or null)
     __shared__ double sh4[4];
     double a = 0.0;
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         const double f = rhs[i];
         r[i] = f; rhat[i] = f; p[i] = f; y[i] = 0.0;
+        if (p32) p32[i] = (float)f;
         a += f * f;
     }
     a = block_sum(a, sh4);
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(kBlock) void k_bicg_s(int64_t n, int it, int max_it
                                                    int np, int rs, const double* red, double* part,
                                                    const double* __restrict__ r, const double* __restrict__ v,
                                                    const double* __restrict__ rhat, double* __restrict__ s,
-                                                   KrylovState* __restrict__ st) {
+                                                   KrylovState* __restrict__ st, float* __restrict__ s32) {
     __shared__ double sh4[4];
     if (st->done) return;
     // ||r||^2 of the iterate that opened this iteration decides whether to go on (the test sits here,
@@ -344,6 +346,7 @@ __global__ __launch_bounds__(kBlock) void k_bicg_s(int64_t n, int it, int max_it
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         const double si = r[i] - alpha * v[i];
         s[i] = si;
+        if (s32) s32[i] = (float)si;
         a += rhat[i] * si;
     }
     a = block_sum(a, sh4);
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(kBlock) void k_bicg_u(int64_t n, int it, int np, in
                                                    const double* __restrict__ s, const double* __restrict__ t,
                                                    const double* __restrict__ v, double* p, const TP* phat,
                                                    const TP* shat, double* __restrict__ y,
-                                                   double* __restrict__ r, KrylovState* __restrict__ st) {
+                                                   double* __restrict__ r, KrylovState* __restrict__ st, float* __restrict__ p32) {
     __shared__ double sh4[4];
     if (st->done) return;
     double ts = 0.0, tt = 0.0, rht = 0.0, rhs = 0.0;
@@ -388,7 +391,9 @@ __global__ __launch_bounds__(kBlock) void k_bicg_u(int64_t n, int it, int np, in
         y[i] += alpha * (double)phat[i] + omega * (double)shat[i];  // phat = M^-1 p, shat = M^-1 s (aliases of p, s for Jacobi)
         const double ri = si - omega * t[i];
         r[i] = ri;
-        p[i] = ri + beta * (pi - omega * v[i]);
+        const double pn = ri + beta * (pi - omega * v[i]);
+        p[i] = pn;
+        if (p32) p32[i] = (float)pn;
         a += ri * ri;
     }
     a = block_sum(a, sh4);
@@ -397,9 +402,9 @@ __global__ __launch_bounds__(kBlock) void k_bicg_u(int64_t n, int it, int np, in
 
 void krylov_init(Ctx* c, const double* rhs) {
     PhaseTimer t(c, SHK_PH_VECTOR);
-    note_bytes(c, 40.0 * (double)c->n_own);
+    note_bytes(c, (c->use_amg ? 44.0 : 40.0) * (double)c->n_own);
     hipLaunchKernelGGL(k_bicg_init, dim3(c->grid), dim3(kBlock), 0, c->stream, c->n_own, rhs, c->d_r, c->d_rhat,
-                       c->d_p, c->d_y, c->d_part, c->d_state);
+                       c->d_p, c->d_y, c->d_part, c->d_state, c->use_amg ? c->d_p32 : nullptr);
 }
 
 // Iterative refinement around BiCGStab (its recursive residual drifts from b - A x over thousands of
@@ -641,27 +646,28 @@ hipError_t krylov_iteration(Ctx* c, int it) {
         hipLaunchKernelGGL(k_krylov_check, dim3(1), b, 0, c->stream, it, c->params.krylov_max_it, c->cur_rtol2, c->cur_atol2,
                            c->np, c->red_stride, c->d_red, c->d_state);
     }
-    if (amg && (e = amg_vcycle(c, *c->amg, c->d_p, c->d_phat)) != hipSuccess) return e;
+    if (amg && (e = amg_vcycle(c, *c->amg, (const float*)c->d_p32, c->d_phat)) != hipSuccess) return e;
     if ((e = krylov_product<1>(c, A, amg ? (const void*)c->d_phat : (const void*)c->d_p, c->d_v, nullptr)) != hipSuccess) return e;
     if ((e = allreduce_parts(c, P_RR, 2)) != hipSuccess) return e;
     {
         PhaseTimer t(c, SHK_PH_VECTOR);
-        note_bytes(c, 32.0 * (double)c->n_own);
+        note_bytes(c, (amg ? 36.0 : 32.0) * (double)c->n_own);
         hipLaunchKernelGGL(k_bicg_s, g, b, 0, c->stream, c->n_own, it, c->params.krylov_max_it, c->cur_rtol2,
-                           c->cur_atol2, c->np, c->red_stride, c->d_red, part, c->d_r, c->d_v, c->d_rhat, c->d_s, c->d_state);
+                           c->cur_atol2, c->np, c->red_stride, c->d_red, part, c->d_r, c->d_v, c->d_rhat, c->d_s, c->d_state,
+                           amg ? c->d_s32 : nullptr);
     }
-    if (amg && (e = amg_vcycle(c, *c->amg, c->d_s, c->d_shat)) != hipSuccess) return e;
+    if (amg && (e = amg_vcycle(c, *c->amg, (const float*)c->d_s32, c->d_shat)) != hipSuccess) return e;
     if ((e = krylov_product<2>(c, A, amg ? (const void*)c->d_shat : (const void*)c->d_s, c->d_t, c->d_s)) != hipSuccess) return e;
     if ((e = allreduce_parts(c, P_TS, 4)) != hipSuccess) return e;
     {
         PhaseTimer t(c, SHK_PH_VECTOR);
-        note_bytes(c, (amg ? 72.0 : 64.0) * (double)c->n_own);
+        note_bytes(c, (amg ? 76.0 : 64.0) * (double)c->n_own);
         if (amg)
             hipLaunchKernelGGL(k_bicg_u<float>, g, b, 0, c->stream, c->n_own, it, c->np, c->red_stride, c->d_red, part, c->d_s, c->d_t, c->d_v,
-                               c->d_p, (const float*)c->d_phat, (const float*)c->d_shat, c->d_y, c->d_r, c->d_state);
+                               c->d_p, (const float*)c->d_phat, (const float*)c->d_shat, c->d_y, c->d_r, c->d_state, c->d_p32);
         else
             hipLaunchKernelGGL(k_bicg_u<double>, g, b, 0, c->stream, c->n_own, it, c->np, c->red_stride, c->d_red, part, c->d_s, c->d_t, c->d_v,
-                               c->d_p, (const double*)c->d_p, (const double*)c->d_s, c->d_y, c->d_r, c->d_state);
+                               c->d_p, (const double*)c->d_p, (const double*)c->d_s, c->d_y, c->d_r, c->d_state, (float*)nullptr);
     }
     return hipSuccess;
 }
