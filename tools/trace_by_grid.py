@@ -6,9 +6,10 @@ import collections, csv, gzip, re, sys
 
 def label(name: str) -> str:
     n = name.split("(")[0].replace("void ", "").replace("shk::", "")
+    head, sep, targs = n.partition("<")   # abbreviate the template arguments only
     for a, b in (("double", "d"), ("float", "f"), ("true", "T"), ("false", "F"), (", ", ",")):
-        n = n.replace(a, b)
-    return n[:44]
+        targs = targs.replace(a, b)
+    return (head + sep + targs)[:44]
 
 
 agg = collections.defaultdict(lambda: [0, 0.0])
