@@ -283,6 +283,8 @@ def main():
             "parallelism": f"dd{world}" if world > 1 else "single",
         },
     }
+    # SELL-64 padding, share of the slots whose columns are 16-bit offsets, multigrid levels on the packed copy (rank 0's context)
+    out["storage"] = run.ctx.storage_stats()
     out["env_overrides"] = switches or None
     out["assembly_passes"] = dict(run.ctx.solver_stats(), note="since context creation (warm-up included): full = residual + Jacobian; "
                                   "residual_only = the pass after the update predicted to be a Newton solve's last (its Jacobian "

@@ -272,6 +272,10 @@ int shk_solver_stats(shk_ctx* ctx, int64_t n[5]);
  * n[9]=multigrid levels (sparse + dense) n[10]=rows of the dense coarsest level
  * n[11]=LDS bytes of one assembly workgroup | (most vertices one stages << 32) */
 int shk_plan_stats(shk_ctx* ctx, int64_t n[12]);
+/* Storage of the Jacobian and of the multigrid's smoother copies: n[0]=stored entries (nnz) n[1]=SELL-64 slots (nnz +
+ * padding) n[2]=slots of slices whose columns are stored as 16-bit offsets n[3]=slices n[4]=sparse multigrid levels
+ * that smooth on a packed bfloat16 copy (level 0 included) n[5]=rows of the largest level that does not. */
+int shk_storage_stats(shk_ctx* ctx, int64_t n[6]);
 
 /* ---- setup-time data ingestion (context-free: host arrays in and out, caller's node order) ----
  * Bilinear interpolation of gridded data to npts points: replaces the RegularGridInterpolator evaluation of

@@ -67,7 +67,7 @@ EXPORTS = (
     "shk_get_params", "shk_set_quadrature", "shk_set_field", "shk_get_field", "shk_set_dirichlet",
     "shk_assemble", "shk_get_residual", "shk_csr_nnz", "shk_get_csr", "shk_linear_solve", "shk_spmv",
     "shk_newton_solve", "shk_update_explicit", "shk_step", "shk_sync", "shk_profile_enable",
-    "shk_profile_read", "shk_time_kernel", "shk_time_assemble_residual", "shk_solver_stats", "shk_plan_stats", "shk_set_halo", "shk_comm_unique_id",
+    "shk_profile_read", "shk_time_kernel", "shk_time_assemble_residual", "shk_solver_stats", "shk_plan_stats", "shk_storage_stats", "shk_set_halo", "shk_comm_unique_id",
     "shk_comm_init_rccl", "shk_comm_init_callbacks", "shk_comm_selftest", "shk_comm_set_timing_only", "shk_comm_mark_stalled", "shk_comm_allreduce_check", "shk_comm_time_round", "shk_env_overrides", "shk_tunable_set", "shk_comm_stats", "shk_comm_overlap", "shk_halo_update", "shk_interp_regular_grid",
     "shk_points_in_polygon",
 )
@@ -120,6 +120,7 @@ def load():
         "shk_plan_stats": ([vp, P(i64)], C.c_int),
         "shk_time_assemble_residual": ([vp, i32, dbl, P(dbl)], C.c_int),
         "shk_solver_stats": ([vp, P(i64)], C.c_int),
+        "shk_storage_stats": ([vp, P(i64)], C.c_int),
         "shk_set_halo": ([vp, i32, vp, vp, vp, vp], C.c_int),
         "shk_comm_unique_id": ([vp], C.c_int),
         "shk_comm_init_rccl": ([vp, i32, i32, vp], C.c_int),
@@ -472,6 +473,14 @@ class ShaktiHip:
         return dict(assemblies_full=int(n[0]), assemblies_residual_only=int(n[1]), assemblies_redone=int(n[2]),
                     linear_solves_forced=int(n[4]),
                     newton_its_last_solve=int(n[3]))
+
+    def storage_stats(self) -> dict:
+        n = (C.c_int64 * 6)()
+        self._check(self.lib.shk_storage_stats(self._h, n))
+        nnz, slots, slots16 = int(n[0]), int(n[1]), int(n[2])
+        return dict(nnz=nnz, sell_slots=slots, sell_padding=slots / max(nnz, 1) - 1.0, slices=int(n[3]),
+                    slots_with_16bit_columns=slots16, col16_coverage=slots16 / max(slots, 1),
+                    levels_on_packed_bf16_copy=int(n[4]), largest_level_on_float_values=int(n[5]))
 
     def plan_stats(self) -> dict:
         n = (C.c_int64 * 12)()

@@ -1326,4 +1326,21 @@ int shk_plan_stats(shk_ctx* ctx, int64_t n[12]) {
     return 0;
 }
 
+int shk_storage_stats(shk_ctx* ctx, int64_t n[6]) {
+    CHECK_CTX(ctx);
+    if (!n) return fail("null output");
+    const Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    n[0] = c->nnz; n[1] = c->slots; n[2] = c->slots16; n[3] = c->plan.A.nslice;
+    const AmgHierarchy& H = c->amg ? *c->amg : c->amg_local;
+    int64_t packed = c->d_pk ? 1 : 0, largest_float = c->d_pk ? 0 : c->n_own;
+    if (H.ready())
+        for (size_t l = 1; l < H.lv.size(); ++l) {
+            if (H.lv[l].n <= 0) continue;
+            if (H.lv[l].pk) ++packed;
+            else largest_float = std::max<int64_t>(largest_float, H.lv[l].n);
+        }
+    n[4] = packed; n[5] = largest_float;
+    return 0;
+}
+
 }  // extern "C"

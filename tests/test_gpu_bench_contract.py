@@ -46,6 +46,10 @@ def test_bench_line_has_every_contract_field():
     assert roof["kernels"]["assemble"]["bound"] == "fp64 valu"
     assert set(d["windows"]) >= {"steps_1_8", "steps_5_24", "per_step"} and d["windows"]["steps_1_8"]["newton_its"] > 0
     assert d["env_overrides"] is None and d["assembly_passes"]["assemblies_full"] > 0
+    # ... and the storage figures VERDICT r02 item 7 asked for beside the kernel times, the inexact-Newton rule in the config
+    st = d["storage"]
+    assert 0 <= st["sell_padding"] < 0.5 and 0.5 < st["col16_coverage"] <= 1 and st["sell_slots"] >= st["nnz"] > 0
+    assert d["config"]["krylov_forcing"] == 0.1 and "linear_solves_forced" in d["assembly_passes"]
 
 
 def test_bench_line_of_a_two_rank_launch_reports_every_rank():
