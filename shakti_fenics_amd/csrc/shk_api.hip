@@ -691,10 +691,18 @@ static int krylov_inner(Ctx* c, const double* rhs, int max_it, KrylovState* out)
     int it = 0, slot = 0;
     const int saved_max = c->params.krylov_max_it;
     c->params.krylov_max_it = max_it;
+    // while profiling: the event-pool position at which every enqueued iteration begins, so that the launches queued
+    // behind the stop flag can be taken out of the profile by POSITION once the run knows where it stopped.  (Their
+    // duration alone does not identify them: a launch that returns at once measures 2-5 us, the small multigrid levels'
+    // real kernels 6-10 us -- and counted as launches of 3-5 us they diluted the average k_spmv launch of the profiled
+    // step from ~190 to ~140 us until this was found in a kernel trace of that step.)
+    std::vector<size_t> iter_ev;
     auto enqueue = [&](int sl, int n) -> hipError_t {
         hipError_t e = hipSuccess;
-        for (int k = 0; k < n; ++k)
+        for (int k = 0; k < n; ++k) {
+            if (c->profiling) iter_ev.push_back(c->ev_used);
             if ((e = krylov_iteration(c, it + k)) != hipSuccess) return e;
+        }
         it += n;
         e = hipMemcpyAsync(&c->h_state[sl], c->d_state, sizeof(KrylovState), hipMemcpyDeviceToHost,
                                       c->stream);
@@ -733,6 +741,16 @@ static int krylov_inner(Ctx* c, const double* rhs, int max_it, KrylovState* out)
     c->params.krylov_max_it = saved_max;
     if (e == hipErrorLaunchTimeOut) return fail(kStallMsg);
     if (e != hipSuccess) return fail(std::string("krylov enqueue: ") + hipGetErrorString(e));
+    if (c->profiling && rc == 0 && out->done && out->its >= 0 && (size_t)out->its < iter_ev.size()) {
+        // iterations 0 .. its-1 ran; everything queued for iterations > its returned at once.  Iteration `its` itself: with
+        // the early stop test only its first launch (k_krylov_check) did any work; without it the cycle and the product that
+        // open the iteration ran and the rest returned at once (those keep the duration filter of shk_profile_read).
+        const size_t its = (size_t)out->its;
+        const size_t later = its + 1 < iter_ev.size() ? iter_ev[its + 1] : c->ev_used;
+        for (size_t i = later; i < c->ev_used; ++i) c->ev_pool[i].phase = -1;
+        const bool early = c->use_amg && (c->comm.kind == Comm::NONE || c->comm.nranks <= 1) && tunables().krylov_early_check;
+        if (early) for (size_t i = iter_ev[its] + 1; i < later; ++i) c->ev_pool[i].phase = -1;
+    }
     return rc;
 }
 
@@ -1235,6 +1253,7 @@ int shk_profile_read(shk_ctx* ctx, shk_profile* out, int32_t reset) {
     for (size_t i = 0; i < c->ev_used; ++i) {
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, c->ev_pool[i].a, c->ev_pool[i].b));
+        if (c->ev_pool[i].phase < 0) continue;   // queued behind a Krylov stop flag (krylov_inner marks them by position)
         if (ms < 0.003f) continue;   // a launch that returned at once behind a solver's stop flag (~1 us)
         c->prof.ms[c->ev_pool[i].phase] += ms;
         c->prof.launches[c->ev_pool[i].phase] += 1;
