@@ -1268,7 +1268,7 @@ static bool launch_sweeps(Ctx* c, const DevSweepPlan& S, const DevSell& A, const
 // z = M^-1 r : one V(0,2) cycle.  r and z have the fine level's length; r is not modified.  TR: double for a context's
 // own hierarchies (the Krylov vector), float for the replicated hierarchy (the gathered right-hand side).
 template <class TR>
-static hipError_t amg_vcycle_t(Ctx* c, AmgHierarchy& H, const TR* rin, float* zout) {
+static hipError_t amg_vcycle_t(Ctx* c, AmgHierarchy& H, const TR* rin, float* zout, const double* rin_last = nullptr) {
     const int32_t n_top = H.topA.n_rows, ncol_top = H.topA.n_cols;
     const size_t nx = H.xf.size();  // levels 0..nx-1 are sparse, level nx is the dense coarsest
     const int* done = &c->d_state->done;
@@ -1449,7 +1449,10 @@ static hipError_t amg_vcycle_t(Ctx* c, AmgHierarchy& H, const TR* rin, float* zo
             }
             if (!split_done) {
                 if (halo && !frozen && (e = halo_exchange_plan_f32(c, *HP, H.x0)) != hipSuccess) return e;
-                launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)H.x0, zout, w2, done, ph(SHK_PH_AMG_FINE), a_bytes);
+                // (rin_last: the cycle's LAST sweep reads the double right-hand side instead of its float copy, so that the
+                //  consumer that follows finds it warm in the Infinity Cache: amg_vcycle below)
+                if (rin_last && !four) launch_post<true>(c, A, H.top_vals, H.top_dinv, rin_last, (const float*)H.x0, zout, w2, done, ph(SHK_PH_AMG_FINE), a_bytes);
+                else launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)H.x0, zout, w2, done, ph(SHK_PH_AMG_FINE), a_bytes);
             }
             if (four) {
                 launch_post<true>(c, A, H.top_vals, H.top_dinv, rin, (const float*)zout, H.x0, (float)(H.c4[2] / l4), done, ph(SHK_PH_AMG_FINE), a_bytes);
@@ -1553,7 +1556,12 @@ hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout) {
 // The Krylov loop hands the cycle the float copies its vector kernels write beside p and s (Ctx::d_p32, d_s32): the cycle
 // reads its right-hand side three times on the finest level (restriction, first sweep, second sweep) and rounds it to
 // float on the way in either way.
-hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const float* rin, float* zout) { return amg_vcycle_t<float>(c, H, rin, zout); }
+// rin_last (optional): the same vector in double.  The cycle's last sweep then reads IT: 40 MB more for that sweep, but the
+// Krylov product that follows the cycle on s needs s itself (the dot products t.s, rhat.t are taken in double) and found it
+// cold once the cycle stopped touching it: k_spmv<2> 150 -> 198 us at 10M rows beside k_spmv<1>'s 176.
+hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const float* rin, float* zout, const double* rin_last) {
+    return amg_vcycle_t<float>(c, H, rin, zout, rin_last);
+}
 
 // ------------------------------------------------------------------ distributed setup (collective)
 // One integer per row of a level travels as a double through that level's halo plan.

@@ -705,7 +705,7 @@ hipError_t allgather_blocks(Ctx* c, void* buf, const std::vector<int64_t>& off);
 int amg_setup_distributed(Ctx* c, std::string& err);  // collective
 hipError_t amg_numeric_setup(Ctx* c, AmgHierarchy& H, bool refresh_dense, bool decided = false, bool top_only = false);
 hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const double* rin, float* zout);
-hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const float* rin, float* zout);
+hipError_t amg_vcycle(Ctx* c, AmgHierarchy& H, const float* rin, float* zout, const double* rin_last = nullptr);
 // upload one host hierarchy (shk_api.hip: owns the allocation helpers)
 hipError_t amg_upload(Ctx* c, std::vector<AmgLevelPlan>& plans, AmgHierarchy& H, int64_t n_loc0,
                       const std::vector<int32_t>* krank0 = nullptr,    // krank0: k-d ranks of the top rows (default: the mesh's)

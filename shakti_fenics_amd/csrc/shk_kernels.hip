@@ -656,7 +656,7 @@ hipError_t krylov_iteration(Ctx* c, int it) {
                            c->cur_atol2, c->np, c->red_stride, c->d_red, part, c->d_r, c->d_v, c->d_rhat, c->d_s, c->d_state,
                            amg ? c->d_s32 : nullptr);
     }
-    if (amg && (e = amg_vcycle(c, *c->amg, (const float*)c->d_s32, c->d_shat)) != hipSuccess) return e;
+    if (amg && (e = amg_vcycle(c, *c->amg, (const float*)c->d_s32, c->d_shat, tunables().amg_warm_s ? c->d_s : nullptr)) != hipSuccess) return e;
     if ((e = krylov_product<2>(c, A, amg ? (const void*)c->d_shat : (const void*)c->d_s, c->d_t, c->d_s)) != hipSuccess) return e;
     if ((e = allreduce_parts(c, P_TS, 4)) != hipSuccess) return e;
     {

@@ -50,6 +50,7 @@ struct Tunables {
     int warm_its = 3;             // SHK_WARM_ITS     Newton iterations of a step that are warm-started (1..3)
     int krylov_chunk = 0;         // SHK_KRYLOV_CHUNK iterations enqueued per stop-flag poll (0 = automatic)
     double krylov_near = 0.0;     // SHK_KRYLOV_NEAR  stop queueing ahead within that factor of the target (0 = off)
+    bool amg_warm_s = true;           // SHK_AMG_WARM_S  0: the cycle on s reads only the float copy (k_spmv<2> then finds s cold)
     bool krylov_early_check = true;   // SHK_KRYLOV_EARLY_CHECK 0: the stop test only inside k_bicg_s (one cycle + product later)
     int predict_last = 1;         // SHK_PREDICT_LAST 0: every Newton iteration ends with a full residual + Jacobian pass
     // communication
@@ -111,6 +112,7 @@ inline bool tunable_apply(Tunables& t, const std::string& name, const char* s) {
     if (name == "SHK_WARM_ITS") { I(t.warm_its); if (t.warm_its < 1) t.warm_its = 1; return true; }
     if (name == "SHK_KRYLOV_CHUNK") return I(t.krylov_chunk);
     if (name == "SHK_KRYLOV_NEAR") return D(t.krylov_near);
+    if (name == "SHK_AMG_WARM_S") return B(t.amg_warm_s);
     if (name == "SHK_KRYLOV_EARLY_CHECK") return B(t.krylov_early_check);
     if (name == "SHK_PREDICT_LAST") return I(t.predict_last);
     if (name == "SHK_COMM_TIMEOUT_S") return D(t.comm_timeout_s);
@@ -129,7 +131,7 @@ inline const char* const* tunable_names(int* n) {
         "SHK_AMG_DAMP_SCALE", "SHK_AMG_LANCZOS", "SHK_AMG_REUSE", "SHK_AMG_LAMBDA_PERIOD", "SHK_FUSED_RESTRICT",
         "SHK_AMG_FUSED_SWEEPS", "SHK_AMG_FUSED_ROWS", "SHK_AMG_BF16_ROWS", "SHK_AMG_W1", "SHK_AMG_W2", "SHK_AMG_HALO_LEVELS", "SHK_AMG_REP_ROWS",
         "SHK_AMG_GHOST_EXCHANGE", "SHK_AMG_E_EXCHANGE", "SHK_GAL_ILP0", "SHK_GAL_ILP1", "SHK_GAL_GRID0", "SHK_GAL_GRID1", "SHK_GAL_CONTIG0",
-        "SHK_GAL_CONTIG1", "SHK_GJ_PIVOTWISE", "SHK_WARM_ITS", "SHK_KRYLOV_CHUNK", "SHK_KRYLOV_NEAR", "SHK_KRYLOV_EARLY_CHECK", "SHK_PREDICT_LAST",
+        "SHK_GAL_CONTIG1", "SHK_GJ_PIVOTWISE", "SHK_WARM_ITS", "SHK_KRYLOV_CHUNK", "SHK_KRYLOV_NEAR", "SHK_AMG_WARM_S", "SHK_KRYLOV_EARLY_CHECK", "SHK_PREDICT_LAST",
         "SHK_COMM_TIMEOUT_S", "SHK_OVERLAP", "SHK_DEBUG", "SHK_ASM_ABLATE"};
     *n = (int)(sizeof(names) / sizeof(names[0]));
     return names;
