@@ -216,7 +216,7 @@ class SingleRunner:
                                  / (t_in * 1e-3) / 1e9 if t_in > 0 else 0.0},
                  "launches": {"assemble": ph["assemble"]["launches"], "spmv": ph["spmv"]["launches"]},
                  "note": "a mix figure: the assembly is bound by fp64 issue (~14 % of the HBM roofline), the product runs at "
-                         "~75-80 %, so the aggregate falls as a step needs fewer Krylov iterations per assembly"}
+                         "~65-80 % depending on the box, so the aggregate falls as a step needs fewer Krylov iterations per assembly"}
         for v in (inner["needed"], inner["algorithmic"]):
             v["frac"] = v["achieved"] / peak_gbs
         inner["achieved"], inner["frac"] = inner["needed"]["achieved"], inner["needed"]["frac"]
