@@ -205,9 +205,16 @@ class SingleRunner:
         c.assemble(self.dt)
         b2b_ms = c.time_kernel("spmv", 20)
         need_spmv = d["bytes_per_launch"] if dom == "spmv" else legs["spmv"]["bytes_per_launch"]
+        st = c.storage_stats()   # what k_spmv<0> has to move: values + (16- or 32-bit) columns + slice descriptors + double x and y
+        need_b2b = (8 * st["sell_slots"] + 2 * st["slots_with_16bit_columns"] + 4 * (st["sell_slots"] - st["slots_with_16bit_columns"])
+                    + 16 * st["slices"] + 16 * nv)
         b2b = {"kernel": "k_spmv<0> (same product without the fused dots, double x), 20 launches between one hipEvent pair",
                "avg_launch_ms": b2b_ms, "bytes_per_launch": alg["spmv"],
-               "achieved": alg["spmv"] / (b2b_ms * 1e-3) / 1e9, "frac": alg["spmv"] / (b2b_ms * 1e-3) / 1e9 / peak_gbs}
+               "achieved": alg["spmv"] / (b2b_ms * 1e-3) / 1e9, "frac": alg["spmv"] / (b2b_ms * 1e-3) / 1e9 / peak_gbs,
+               "needed": {"bytes_per_launch": need_b2b, "achieved": need_b2b / (b2b_ms * 1e-3) / 1e9,
+                          "frac": need_b2b / (b2b_ms * 1e-3) / 1e9 / peak_gbs},
+               "note": "`frac` prices this leg with SURVEY.md 8d's algorithmic bytes (as rounds 1-2 did); `needed` with the bytes "
+                       "the kernel has to move, the pricing of `roofline.frac`"}
         # north_star states its target on the "assembly + SpMV inner loop"
         t_in = ph["assemble"]["ms"] + ph["spmv"]["ms"]
         inner = {"definition": "all k_assemble + k_spmv launches of the profiled step: bytes / summed hipEvent durations",
