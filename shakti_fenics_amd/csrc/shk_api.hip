@@ -387,6 +387,7 @@ int shk_create_local(int device_id, int64_t n_own, int64_t n_ghost, int64_t ne, 
     opt.cells_max = std::min(std::max(64, T.asm_cells), kAsmCellsMax);
     opt.slots_max = kAsmSlotsMax;
     opt.sort_window = std::max(64, T.sort_window);
+    opt.rim_first = T.sort_rim;
     opt.reorder = T.reorder;
     opt.amg = T.amg;
     opt.amg_coarsest = T.amg_coarsest;

@@ -31,6 +31,7 @@ struct PlanOptions {
     int cells_max = 640;   // cells staged in LDS by one assembly block
     int slots_max = 3072;  // SELL slots one assembly block may own (its threads preload their plan words)
     int sort_window = 256; // rows per row-length sorting window (multiple of 64)
+    bool rim_first = true;  // among the rows of one length inside a window: those with a neighbour outside it first
     bool reorder = true;   // internal k-d order + window sort (false: keep the caller's numbering)
     bool amg = true;       // also build the aggregation-multigrid hierarchy (of the owned diagonal block)
     int amg_coarsest = 4096; // cap of the dense coarsest level of a local hierarchy (inverted by Gauss-Jordan)

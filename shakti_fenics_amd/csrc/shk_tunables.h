@@ -18,6 +18,7 @@ struct Tunables {
     int asm_slices = 4;           // SHK_ASM_SLICES   slices of 64 rows per assembly workgroup, 1..4 (the kernel's limit)
     int asm_cells = 640;          // SHK_ASM_CELLS    cells one assembly workgroup stages
     int sort_window = 256;        // SHK_SORT_WINDOW  rows per row-length sorting window
+    bool sort_rim = true;         // SHK_SORT_RIM     0: rows of one length inside a window keep their k-d order (rounds 1-2)
     bool reorder = true;          // SHK_REORDER      0: keep the caller's numbering (disables the hierarchy)
     int xcd = -1;                 // SHK_XCD          force the sweep placement (0 streaming, 1 XCD-contiguous); -1 = by size
     // multigrid hierarchy and cycle
@@ -79,6 +80,7 @@ inline bool tunable_apply(Tunables& t, const std::string& name, const char* s) {
     if (name == "SHK_ASM_SLICES") return I(t.asm_slices);
     if (name == "SHK_ASM_CELLS") return I(t.asm_cells);
     if (name == "SHK_SORT_WINDOW") return I(t.sort_window);
+    if (name == "SHK_SORT_RIM") return B(t.sort_rim);
     if (name == "SHK_REORDER") return B(t.reorder);
     if (name == "SHK_XCD") return I(t.xcd);
     if (name == "SHK_AMG") return B(t.amg);
@@ -126,7 +128,7 @@ inline bool tunable_apply(Tunables& t, const std::string& name, const char* s) {
 
 inline const char* const* tunable_names(int* n) {
     static const char* const names[] = {
-        "SHK_ASM_SLICES", "SHK_ASM_CELLS", "SHK_SORT_WINDOW", "SHK_REORDER", "SHK_XCD", "SHK_AMG", "SHK_AMG_COARSEST",
+        "SHK_ASM_SLICES", "SHK_ASM_CELLS", "SHK_SORT_WINDOW", "SHK_SORT_RIM", "SHK_REORDER", "SHK_XCD", "SHK_AMG", "SHK_AMG_COARSEST",
         "SHK_AMG_ALPHA", "SHK_AMG_COARSE4", "SHK_AMG_COARSE4_FROM", "SHK_AMG_DENSE_PERIOD", "SHK_AMG_W_ROWS",
         "SHK_AMG_DAMP_SCALE", "SHK_AMG_LANCZOS", "SHK_AMG_REUSE", "SHK_AMG_LAMBDA_PERIOD", "SHK_FUSED_RESTRICT",
         "SHK_AMG_FUSED_SWEEPS", "SHK_AMG_FUSED_ROWS", "SHK_AMG_BF16_ROWS", "SHK_AMG_W1", "SHK_AMG_W2", "SHK_AMG_HALO_LEVELS", "SHK_AMG_REP_ROWS",
