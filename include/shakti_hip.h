@@ -50,10 +50,12 @@ typedef struct shk_params {
                                    will follow anyway -- the linear solve stops at a true residual of krylov_forcing * e_k
                                    instead of ten digits below ||F_k||: digits the next iteration recovers for free.  The
                                    iteration expected to END the solve is solved as tightly as before, and a solve is only cut
-                                   short when the iteration after it is safely the last (its remainder, predicted from the
-                                   previous solve's quadratic constant, >= 100 x below the threshold) and the history fits (same
-                                   dt, ||F_0|| within a factor 2): the converged state and (in every test) the Newton counts are
-                                   those of exact solves.  Default 0.1; 0 = off */
+                                   short when the history fits (same dt, ||F_0|| within a factor 2), the regime has settled
+                                   (the ratio of the last two solves within a factor 2), the previous solve ended with the
+                                   iteration after this one and well inside its threshold, and that iteration's remainder,
+                                   predicted from the previous solve's quadratic constant, lies >= 100 x below the threshold:
+                                   the converged state and (in every test) the Newton counts are those of exact solves.
+                                   Default 0.1; 0 = off */
     int32_t newton_max_it;
     int32_t krylov_max_it;
     int32_t krylov_check_every; /* iterations enqueued between host stop-flag polls; 0 = automatic */

@@ -611,7 +611,9 @@ struct Ctx {
     static constexpr int kNewtonHist = 16;
     double newton_ratio[kNewtonHist] = {};   // ||F_{k+1}|| / ||F_k|| of the previous shk_newton_solve (0: none): shk_params.krylov_forcing
     double newton_fk[kNewtonHist] = {};      // ... and its ||F_k||
+    double newton_ratio2[kNewtonHist] = {};  // the ratios of the solve before that one (the rule wants a settled regime)
     double newton_hist_f0 = 0.0, newton_hist_dt = 0.0;   // ||F_0|| and dt of the solve that history belongs to
+    double newton_hist_margin = 0.0;                     // its final ||F|| over its stopping threshold (0: did not converge)
     int64_t n_forced = 0;                    // linear solves stopped by the forcing rule (shk_solver_stats)
     int64_t n_asm_full = 0, n_asm_res = 0, n_asm_redo = 0;   // assembly passes: full, residual-only, full after a misprediction
     double assembled_dt = 0.0;
