@@ -488,6 +488,31 @@ def test_packed_bfloat16_smoother_copy_keeps_solution_and_iteration_counts(hip):
         assert abs(a - b) <= max(3, 0.1 * a), (out["0"][0], out["1"][0])
 
 
+def test_early_stop_check_changes_no_bit_and_warm_s_no_result(hip):
+    """SHK_KRYLOV_EARLY_CHECK (one GPU): k_krylov_check takes the stop decision of k_bicg_s one cycle + one product earlier,
+    from the same partial sums in the same order -- the same iteration counts and a bit-identical solution, with or without
+    it.  SHK_AMG_WARM_S (the cycle on s reads the double vector in its last sweep instead of its float copy): the same
+    preconditioner up to the rounding of its right-hand side, so the same solution to the Krylov tolerance."""
+    dom, f, bc, g = make_case(nx=201, ny=101, Lx=40e3, Ly=20e3, moulins=3)
+    out = {}
+    for key, sw in (("default", {}), ("late", dict(SHK_KRYLOV_EARLY_CHECK="0")), ("cold_s", dict(SHK_AMG_WARM_S="0"))):
+        with hip.tunables(**sw):
+            ctx = hip.ShaktiHip(dom.xy, dom.cells)
+            ctx.set_params(precond=hip.PRECOND["amg"])
+            upload(ctx, f, bc, g)
+            its = []
+            for dt in (360.0, 3600.0):
+                ctx.assemble(dt)
+                n, conv, rr = ctx.linear_solve()
+                assert conv
+                its.append(n)
+            out[key] = (its, ctx.get_field("dx"))
+            ctx.close()
+    assert out["default"][0] == out["late"][0] and np.array_equal(out["default"][1], out["late"][1])
+    assert rel_l2(out["cold_s"][1], out["default"][1]) < 1e-8
+    assert all(abs(a - b) <= max(2, 0.1 * a) for a, b in zip(out["default"][0], out["cold_s"][0]))
+
+
 @pytest.mark.parametrize("with_bc", [False, True])
 def test_residual_only_assembly_equals_the_full_pass(hip, with_bc):
     """The residual-only kernel instance (launched for the pass after the update expected to be a Newton solve's last)
