@@ -189,6 +189,32 @@ int main(int argc, char** argv) {
         CHECK("sell_diag_first", diag_first);
         CHECK("sell_distinct_columns", distinct);
     }
+    // order inside a 256-row window: rows by length, longest first, and within one length the rows with a column outside
+    // the window (the rim: what other windows gather) before the interior ones
+    {
+        bool by_length = true, rim_first = true;
+        const int W = 256;
+        for (int w0 = 0; w0 < P.A.n_rows; w0 += W) {
+            const int w1 = std::min(P.A.n_rows, w0 + W);
+            int prev_len = 1 << 30, seen_interior_of_len = 0;
+            for (int i = w0; i < w1; ++i) {
+                const int s = i / kSlice, l = i % kSlice, base = P.A.ptr[s];
+                const int len = P.A.rowlen[i];
+                bool rim = false;
+                for (int k = 0; k < len; ++k) {
+                    const int c = P.A.col[base + k * kSlice + l];
+                    rim = rim || c < w0 || c >= w1;
+                }
+                by_length = by_length && len <= prev_len;
+                if (len != prev_len) seen_interior_of_len = 0;
+                if (!rim) seen_interior_of_len = 1;
+                else rim_first = rim_first && !seen_interior_of_len;
+                prev_len = len;
+            }
+        }
+        CHECK("window_rows_sorted_by_length", by_length);
+        CHECK("window_rim_rows_first_within_a_length", rim_first);
+    }
     // every fine slot of every transfer lands in exactly one coarse slot; aggregates have 1..4 members
     {
         bool cover = true, members = true;
