@@ -899,6 +899,44 @@ static int residual_norm(Ctx* c, double* out) {
     return read_aux_norm(c, out);
 }
 
+// Absolute residual at which the linear solve of Newton iteration `it` may stop (shk_newton_solve): Newton's own floor
+// krylov_newton_eta x T, or -- inexact Newton, shk_params.krylov_forcing -- more, where more cannot change the outcome.
+//   r = ||F_it||, T = Newton's stopping threshold, hist1[k] = ||F_{k+1}|| / ||F_k|| of the previous solve.
+// e = hist1[it] r is what this iteration is expected to leave behind however well its system is solved (the nonlinear
+// remainder).  While e is an order of magnitude above T another iteration follows anyway and inherits a right-hand side of
+// ~e: digits below forcing x e are digits the next iteration recovers for free.  The prediction is only believed where it
+// has earned it; every condition answers a test that took one Newton iteration more than the LU oracle without it:
+//   similar   the history comes from a solve like this one: same dt, ||F_0|| within a factor 2 (a forcing that jumps between
+//             two steps -- moulin input x 20, then off -- moves ||F_0|| by more);
+//   settled   the ratio this iteration left in the last TWO solves within a factor 2 of each other (where the Newton count
+//             is about to drop the ratios change by an order of magnitude per step -- 3.6e-3, 4.8e-4, 4e-5 -- and the rule
+//             cut a solve short at 1.04 T that exact solves finish at 0.9 T; in the settled transient of the bench they
+//             change by 0.5 % per step);
+//   was_last  the previous solve ENDED with the iteration after this one, well inside its threshold (<= 0.3 T: mostly the
+//             linear floor 0.1 T, so that twice the nonlinear part still fits);
+//   pred2     that iteration's remainder, predicted with the previous solve's quadratic constant kappa = ||F_{k+1}|| /
+//             ||F_k||^2 as kappa e^2, lies 100 x below T (an inexact solve enlarges the next right-hand side and that
+//             remainder with its square).
+// The iteration expected to end the solve, and every iteration without such a history, is solved as before.
+static double forcing_floor(Ctx* c, int it, double r, double T, bool similar, const double* hist1) {
+    double floor = c->params.krylov_newton_eta * T;
+    if (!(c->params.krylov_forcing > 0.0) || !similar || it >= Ctx::kNewtonHist) return floor;
+    const double r1 = hist1[it], r2 = c->newton_ratio2[it], fk = c->newton_fk[it];
+    const bool settled = r1 > 0.0 && r2 > 0.0 && r1 < 2.0 * r2 && r2 < 2.0 * r1;
+    if (!settled || !(r1 * r > 10.0 * T)) return floor;
+    const double e = r1 * r;
+    const double pred2 = fk > 0.0 ? (r1 / fk) * e * e : HUGE_VAL;
+    const bool was_last = c->newton_prev == it + 2 && c->newton_hist_margin > 0.0 && c->newton_hist_margin <= 0.3;
+    const double f = c->params.krylov_forcing * std::min(r1, 1e-2) * r;
+    const bool forced = was_last && pred2 < 0.01 * T && f > floor && f > c->params.krylov_rtol * r;
+    if (forced) { floor = f; c->n_forced += 1; }
+    if (tunables().debug)
+        fprintf(stderr, "[shk] newton it %d: ||F|| %.3e (%.3g T), previous solve: %d its, ratio %.3e (before it %.3e), ended at "
+                        "%.3g T; expected after this iteration %.3g T, after the next %.3g T -> linear floor %.3g T%s\n", it, r,
+                r / T, c->newton_prev, r1, r2, c->newton_hist_margin, e / T, pred2 / T, floor / T, forced ? " (inexact)" : "");
+    return floor;
+}
+
 int shk_newton_solve(shk_ctx* ctx, double dt, shk_solve_info* info) {
     CHECK_CTX(ctx);
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
@@ -937,46 +975,10 @@ int shk_newton_solve(shk_ctx* ctx, double dt, shk_solve_info* info) {
         // iteration is unaffected: 0.1 x 1e-9 ||F_0|| = krylov_rtol ||F_0||).  Newton counts stay those of the LU oracle
         // in every parity test; 0 restores the pure relative rule.
         const double newton_target = std::max(c->params.newton_atol, c->params.newton_rtol * I.residual0);
-        // (an iterate whose residual is already 1e-3 of the step's first one has barely moved: the multigrid keeps its coarse
-        // operators, amg_numeric_setup's top_only)
-        // Inexact Newton (shk_params.krylov_forcing): e = what this iteration left behind in the previous solve, scaled to
-        // this one's ||F_k||.  While e is an order of magnitude above Newton's threshold another iteration follows whatever
-        // this linear solve achieves, and it inherits a right-hand side of ~e either way: solving below forcing * e buys
-        // nothing.  The iteration expected to end the solve (e within 10 x of the threshold, or no history) is untouched.
-        // The history only speaks for a solve that resembles the one it came from: same dt, ||F_0|| within a factor 2
-        // (a forcing that jumps between two steps -- tests: moulin input x 20, then off -- moves ||F_0|| by more).
-        double floor = c->params.krylov_newton_eta * newton_target;
-        // ... and the regime must have settled: the ratio this iteration left in the last TWO solves within a factor 2 of
-        // each other.  (Where the Newton count is about to drop the ratios change by an order of magnitude from one step to
-        // the next -- 3.6e-3, 4.8e-4, 4e-5 in the run that cost an iteration -- and say nothing about the next one; in the
-        // settled transient of the bench they change by 0.5 % per step.)
-        const double r2 = it < Ctx::kNewtonHist ? c->newton_ratio2[it] : 0.0;
-        const bool settled = it < Ctx::kNewtonHist && r2 > 0.0 && hist1[it] < 2.0 * r2 && r2 < 2.0 * hist1[it];
-        const double ratio = (similar && settled) ? hist1[it] : 0.0;
-        if (c->params.krylov_forcing > 0.0 && ratio > 0.0 && ratio * r > 10.0 * newton_target) {
-            // ... and the iteration AFTER this one must be safely the last: an inexact solve here enlarges the next
-            // right-hand side (by ~10 % in the residual norm, possibly more in the error norm), and the remainder of the
-            // following iteration with its square.  If that remainder -- predicted from the previous solve's quadratic
-            // constant kappa = ||F_{k+1}|| / ||F_k||^2 as kappa e^2 -- is not at least 100 x below Newton's threshold, the
-            // enlargement could cost an extra Newton iteration (seen once: 2 subdomains, step 4 of a 5-step run, 3
-            // iterations where exact solves take 2).  Then this solve stays exact.
-            const double e = ratio * r, fk = c->newton_fk[it];
-            const double pred2 = fk > 0.0 ? (ratio / fk) * e * e : HUGE_VAL;
-            const double f = c->params.krylov_forcing * std::min(ratio, 1e-2) * r;
-            // The quadratic constant is not to be trusted alone where Newton does not converge quadratically (the Reynolds
-            // switch, |b|, the clamps): in the same 5-step run the model promised 1e-3 T while the previous solve had needed
-            // a third iteration.  So the previous solve must also have ENDED with the iteration after this one, and ended
-            // well inside the threshold (<= 0.3 T: its last residual then is mostly the linear floor 0.1 T, and twice the
-            // nonlinear part still fits).  The first solve after the Newton count drops is therefore solved exactly.
-            const bool was_last = c->newton_prev == it + 2 && c->newton_hist_margin > 0.0 && c->newton_hist_margin <= 0.3;
-            if (was_last && pred2 < 0.01 * newton_target && f > floor && f > c->params.krylov_rtol * r) { floor = f; c->n_forced += 1; }
-            if (tunables().debug)
-                fprintf(stderr, "[shk] newton it %d: ||F|| %.3e (x T %.3g), previous solve: %d its, ratio %.3e, ended at %.3g T; expected "
-                                "after this iteration %.3g T, after the next %.3g T -> linear floor %.3g T%s\n", it, r, r / newton_target,
-                        c->newton_prev, ratio, c->newton_hist_margin, e / newton_target, pred2 / newton_target, floor / newton_target,
-                        floor == f ? " (inexact)" : "");
-        }
+        const double floor = forcing_floor(c, it, r, newton_target, similar, hist1);
         const double r_before = r;
+        // (an iterate whose residual is already 1e-3 of the step's first one has barely moved: the multigrid keeps its coarse
+        //  operators, amg_numeric_setup's top_only)
         if (krylov_solve(c, &k, &kc, &rr, it, floor, r, it > 0 && r < 1e-3 * I.residual0)) return -1;
         I.krylov_its += k;
         // a solve that stagnated between krylov_rtol and krylov_fail_rtol sits on its fp64 floor
